@@ -1,0 +1,121 @@
+"""Seeded synthetic image sets for the BASELINE.json configs (no network, no reference data).
+
+The reference's example data cannot be downloaded (run_test.py:43 needs the network), so every
+config is restated as a procedural scene: a large textured "world" canvas (sum of anisotropic
+Gaussian blobs + multi-octave value noise, which gives SIFT a realistic 0.5-3 k keypoints per
+0.6 MP working image) from which overlapping views are cut under small seeded homographies.
+float32 RGB in [0,1], HWC -- the reference's ``Mat32f`` layout (lib/mat.h:8-57).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _value_noise(rng, h, w, octaves=6):
+    out = np.zeros((h, w), np.float32)
+    amp = 1.0
+    for o in range(octaves):
+        gh, gw = max(2, h >> (octaves - o)), max(2, w >> (octaves - o))
+        g = rng.random((gh + 1, gw + 1), dtype=np.float32)
+        ys = np.linspace(0, gh, h, endpoint=False, dtype=np.float32)
+        xs = np.linspace(0, gw, w, endpoint=False, dtype=np.float32)
+        y0 = ys.astype(np.int32); x0 = xs.astype(np.int32)
+        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        out += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+        amp *= 0.6
+    out -= out.min(); out /= max(out.max(), 1e-6)
+    return out
+
+
+def make_world(seed: int, h: int, w: int, work_scale: float = 1.0, density: float = 350.0) -> np.ndarray:
+    """Textured RGB canvas, float32 HWC in [0,1].
+
+    ``work_scale`` = SIFT working-size ratio of the views that will be cut from it
+    (``1600 / (view_h + view_w)``, feature.cc:33); blob sizes/density are specified in
+    *working* pixels (one blob per ``density`` working px^2, sigma 1.3-4.5 working px) so
+    every config yields ~0.9 k keypoints per view, like the reference's natural textures.
+    """
+    rng = np.random.default_rng(seed)
+    sc = float(work_scale)
+    img = np.stack([_value_noise(rng, h, w) for _ in range(3)], axis=-1) * 0.3 + 0.35
+    nblobs = int(h * w * sc * sc / density)
+    cy = rng.uniform(0, h, nblobs); cx = rng.uniform(0, w, nblobs)
+    sy = rng.uniform(1.3, 4.5, nblobs) / sc; sx = sy * rng.uniform(0.6, 1.6, nblobs)
+    amp = rng.uniform(-0.65, 0.65, (nblobs, 3)).astype(np.float32)
+    for i in range(nblobs):
+        r = int(3 * max(sy[i], sx[i])) + 1
+        y0, y1 = max(0, int(cy[i]) - r), min(h, int(cy[i]) + r + 1)
+        x0, x1 = max(0, int(cx[i]) - r), min(w, int(cx[i]) + r + 1)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        yy = np.arange(y0, y1, dtype=np.float32)[:, None] - cy[i]
+        xx = np.arange(x0, x1, dtype=np.float32)[None, :] - cx[i]
+        g = np.exp(-(yy * yy) / (2 * sy[i] ** 2) - (xx * xx) / (2 * sx[i] ** 2)).astype(np.float32)
+        img[y0:y1, x0:x1] += g[..., None] * amp[i]
+    # sharp-edged bars: exercise the edge-response and contrast rejections (extrema.cc:152-168, :94)
+    nbars = nblobs // 8
+    by = rng.uniform(0, h, nbars); bx = rng.uniform(0, w, nbars)
+    bl = rng.uniform(12, 60, nbars) / sc; bw = rng.uniform(1.0, 4.0, nbars) / sc
+    ba = rng.uniform(0, np.pi, nbars)
+    bamp = rng.uniform(-0.5, 0.5, (nbars, 3)).astype(np.float32)
+    for i in range(nbars):
+        r = int(bl[i]) + 2
+        y0, y1 = max(0, int(by[i]) - r), min(h, int(by[i]) + r + 1)
+        x0, x1 = max(0, int(bx[i]) - r), min(w, int(bx[i]) + r + 1)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        yy = np.arange(y0, y1, dtype=np.float32)[:, None] - by[i]
+        xx = np.arange(x0, x1, dtype=np.float32)[None, :] - bx[i]
+        u = xx * np.cos(ba[i]) + yy * np.sin(ba[i]); v = -xx * np.sin(ba[i]) + yy * np.cos(ba[i])
+        m = np.clip(bl[i] - np.abs(u), 0, 1) * np.clip(bw[i] - np.abs(v), 0, 1)
+        img[y0:y1, x0:x1] += m[..., None].astype(np.float32) * bamp[i]
+    return np.clip(img, 0.0, 1.0).astype(np.float32)
+
+
+def _bilinear_sample(world, ys, xs):
+    h, w, _ = world.shape
+    ys = np.clip(ys, 0, h - 1.001); xs = np.clip(xs, 0, w - 1.001)
+    y0 = np.floor(ys).astype(np.int32); x0 = np.floor(xs).astype(np.int32)
+    fy = (ys - y0)[..., None].astype(np.float32); fx = (xs - x0)[..., None].astype(np.float32)
+    return (world[y0, x0] * (1 - fx) + world[y0, x0 + 1] * fx) * (1 - fy) + \
+           (world[y0 + 1, x0] * (1 - fx) + world[y0 + 1, x0 + 1] * fx) * fy
+
+
+def cut_view(world, top, left, h, w, seed, rot_deg=2.0, persp=1e-4):
+    """One h x w view of ``world`` at (top,left) under a small seeded homography."""
+    rng = np.random.default_rng(seed)
+    a = np.deg2rad(rng.uniform(-rot_deg, rot_deg))
+    H = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0],
+                  [rng.uniform(-persp, persp), rng.uniform(-persp, persp), 1.0]])
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64) - h / 2, np.arange(w, dtype=np.float64) - w / 2, indexing="ij")
+    z = H[2, 0] * xx + H[2, 1] * yy + 1.0
+    sx = (H[0, 0] * xx + H[0, 1] * yy) / z + left + w / 2
+    sy = (H[1, 0] * xx + H[1, 1] * yy) / z + top + h / 2
+    return np.ascontiguousarray(_bilinear_sample(world, sy, sx).astype(np.float32))
+
+
+def image_set(n: int, h: int, w: int, seed: int, overlap: float = 0.45, rows: int = 1, shuffle: bool = False):
+    """``n`` overlapping h x w views on a ``rows`` x ceil(n/rows) grid over one world canvas."""
+    cols = -(-n // rows)
+    step_x = int(w * (1 - overlap)); step_y = int(h * (1 - overlap))
+    margin = 24
+    world = make_world(seed, step_y * (rows - 1) + h + 2 * margin, step_x * (cols - 1) + w + 2 * margin,
+                       work_scale=1600.0 / (h + w))
+    views = []
+    for i in range(n):
+        r, c = divmod(i, cols)
+        views.append(cut_view(world, margin + r * step_y, margin + c * step_x, h, w, seed * 100 + i))
+    if shuffle:
+        order = np.random.default_rng(seed).permutation(n)
+        views = [views[j] for j in order]
+    return views
+
+
+# BASELINE.json configs restated
+CONFIGS = {
+    "cfg1_2x600x400_cyl": dict(n=2, h=400, w=600, seed=11, overlap=0.58),
+    "cfg2_11x600x400": dict(n=11, h=400, w=600, seed=22, overlap=0.40),
+    "cfg3_13x1500x1112": dict(n=13, h=1112, w=1500, seed=33, overlap=0.40),
+    "cfg4_38x1300x867": dict(n=38, h=867, w=1300, seed=38, overlap=0.45, rows=2, shuffle=True),
+}

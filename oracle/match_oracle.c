@@ -1,0 +1,69 @@
+/* oracle/match_oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Restatement of the reference's exact brute-force matcher, FeatureMatcher::match
+ * (feature/matcher.cc:15-71) and of the SSE squared-L2 it is built on
+ * (feature/dist.cc:22-57, the variant every -march=native x86 build selects).
+ */
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* feature/dist.cc:22-57: four stride-4 partial sums (one per SSE lane), horizontal add
+ * (v0+v1)+(v2+v3); early-out check after elements 4, 36, 68, 100 (n % 32 == 0 with n counting
+ * down from 128) returning FLT_MAX when the partial already exceeds now_thres. */
+float orc_euclidean_sqr(const float* x, const float* y, int n, float now_thres) {
+	float v0 = 0, v1 = 0, v2 = 0, v3 = 0, d;
+	for (; n > 0; n -= 4) {
+		d = x[0] - y[0]; v0 += d * d;
+		d = x[1] - y[1]; v1 += d * d;
+		d = x[2] - y[2]; v2 += d * d;
+		d = x[3] - y[3]; v3 += d * d;
+		if (n % 32 == 0) {
+			float ans = (v0 + v1) + (v2 + v3);
+			if (ans > now_thres) return FLT_MAX;
+		}
+		x += 4; y += 4;
+	}
+	return (v0 + v1) + (v2 + v3);
+}
+
+static int pair_cmp(const void* a, const void* b) {
+	const int* p = (const int*)a; const int* q = (const int*)b;
+	if (p[0] != q[0]) return p[0] < q[0] ? -1 : 1;
+	if (p[1] != q[1]) return p[1] < q[1] ? -1 : 1;
+	return 0;
+}
+
+/* feature/matcher.cc:15-71.  out_pairs holds 2*min(n1,n2) ints; result sorted by (first,second)
+ * (the reference's order is thread-timing dependent, matcher.cc:65). Returns #matches. */
+int orc_match_exact(const orc_sift_cfg* cfg, const float* d1, int n1, const float* d2, int n2, int* out) {
+	const float REJECT_RATIO_SQR = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;
+	int l1 = n1, l2 = n2;
+	int rev = l1 > l2;
+	const float *pf1 = d1, *pf2 = d2;
+	if (rev) { l1 = n2; l2 = n1; pf1 = d2; pf2 = d1; }
+	int cnt = 0;
+	for (int k = 0; k < l1; ++k) {
+		const float* dsc1 = pf1 + 128 * (size_t)k;
+		int min_idx = -1;
+		float min = FLT_MAX, next_min = min;
+		for (int kk = 0; kk < l2; ++kk) {
+			float dist = orc_euclidean_sqr(dsc1, pf2 + 128 * (size_t)kk, 128, next_min);
+			if (dist < min) { next_min = min; min = dist; min_idx = kk; }
+			else if (dist < next_min) next_min = dist;
+		}
+		if (min > REJECT_RATIO_SQR * next_min) continue;
+		const float* dsc2 = pf2 + 128 * (size_t)min_idx;
+		for (int kk = 0; kk < l1; ++kk) if (kk != k) {
+			float dist = orc_euclidean_sqr(dsc2, pf1 + 128 * (size_t)kk, 128, next_min);
+			if (dist < next_min) next_min = dist;
+		}
+		if (min > REJECT_RATIO_SQR * next_min) continue;
+		if (rev) { out[2 * cnt] = min_idx; out[2 * cnt + 1] = k; }
+		else { out[2 * cnt] = k; out[2 * cnt + 1] = min_idx; }
+		cnt++;
+	}
+	qsort(out, cnt, 2 * sizeof(int), pair_cmp);
+	return cnt;
+}

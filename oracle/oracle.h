@@ -1,0 +1,81 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the OpenPano hot path (SIFT -> match -> RANSAC -> warp/blend).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * liboracle.so; the product (openpano_amd/, libopenpano_hip.so) never does.
+ *
+ * Parity status: PINNED.  The reference holds no golden vectors of its own,
+ * so every function here is checked bit-for-bit (integer outputs, fp32 planes, descriptors)
+ * against the reference's own sources compiled in place (oracle/_ref, tests/test_oracle_vs_ref.py)
+ * and against the fixtures that build generated (tests/golden/, made by
+ * tests/golden/make_golden.py).  The one unpinned boundary is the reference's use of the
+ * system Eigen (absent here): FullPivLU 3x3 inverse and JacobiSVD least squares are restated
+ * from their published algorithms (see oracle/ref_shim/Eigen/Dense and DESIGN.md).
+ *
+ * All citations are file:line in /root/reference/src.
+ */
+#ifndef OPENPANO_ORACLE_H
+#define OPENPANO_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirror of namespace config (lib/config.hh:24-85), SIFT/match part; filled from floats
+ * exactly like init_config() (main.cc:237-292) */
+typedef struct {
+	int SIFT_WORKING_SIZE, NUM_OCTAVE, NUM_SCALE;
+	float SCALE_FACTOR, GAUSS_SIGMA;
+	int GAUSS_WINDOW_FACTOR;
+	float JUDGE_EXTREMA_DIFF_THRES, CONTRAST_THRES, PRE_COLOR_THRES, EDGE_RATIO;
+	int CALC_OFFSET_DEPTH;
+	float OFFSET_THRES;
+	float ORI_RADIUS;
+	int ORI_HIST_SMOOTH_COUNT;
+	int DESC_HIST_SCALE_FACTOR, DESC_INT_FACTOR;
+	float MATCH_REJECT_NEXT_RATIO;
+} orc_sift_cfg;
+
+void orc_sift_cfg_default(orc_sift_cfg* c);	/* src/config.cfg:19-49 */
+
+/* ---- staged SIFT run: SIFTDetector::do_detect_feature (feature/feature.cc:31-47) ---- */
+typedef struct orc_sift_run orc_sift_run;
+orc_sift_run* orc_sift_new(const orc_sift_cfg* cfg, const float* rgb, int h, int w);
+void orc_sift_free(orc_sift_run*);
+void orc_sift_working_dims(const orc_sift_run*, int* h, int* w);
+void orc_sift_octave_dims(const orc_sift_run*, int oct, int* h, int* w);
+/* kind: 0 gaussian stack (s=0 grey base), 1 DoG, 2 mag, 3 ort, 4 working RGB */
+int orc_sift_plane(const orc_sift_run*, int kind, int oct, int s, float* out);
+int orc_sift_raw_count(const orc_sift_run*, int oct, int s);
+void orc_sift_raw(const orc_sift_run*, int oct, int s, int* xy);
+/* which: 0 refined, 1 oriented; ints: x,y,pyr,scale; real: real_coor; fl: dir, scale_factor */
+int orc_sift_kp_count(const orc_sift_run*, int which);
+void orc_sift_kp(const orc_sift_run*, int which, int* ints, double* real, float* fl);
+int orc_sift_desc_count(const orc_sift_run*);
+void orc_sift_desc(const orc_sift_run*, float* desc, double* coor);
+
+/* FeatureDetector::detect_feature (feature/feature.cc:20-28): descriptors + centred coords.
+ * Returns K; *desc (K*128 floats) and *coor (K*2 doubles) are malloc'd, free with orc_free. */
+int orc_detect_feature(const orc_sift_cfg* cfg, const float* rgb, int h, int w,
+		float** desc, double** coor);
+void orc_free(void* p);
+/* body of StitcherBase::calc_feature (stitch/stitcherbase.cc:14-25) over n equal-size images */
+long orc_calc_feature_batch(const orc_sift_cfg* cfg, const float* rgb, int n, int h, int w, int nthreads);
+
+/* GaussCache (feature/gaussian.cc:17-40) */
+int orc_gauss_kernel(const orc_sift_cfg* cfg, float sigma, float* out);
+
+/* glibc-compatible scalar kernels that the HIP side re-implements in fp64 (tests compare the
+ * twins below with libm over exhaustive float ranges, and the device against the twins) */
+float orc_expf_twin(float x);
+float orc_cosf_twin(float x);
+float orc_sinf_twin(float x);
+float orc_hypotf_twin(float x, float y);
+
+/* ---- exact matcher: FeatureMatcher::match (feature/matcher.cc:15-71) ---- */
+float orc_euclidean_sqr(const float* x, const float* y, int n, float now_thres);	/* feature/dist.cc:22-57 */
+int orc_match_exact(const orc_sift_cfg* cfg, const float* d1, int n1, const float* d2, int n2, int* out_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,240 @@
+// oracle/ref_driver.cc -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// extern "C" accessors over the *unmodified* reference classes, compiled together with
+// the reference's own translation units (in place, from /root/reference/src) into
+// oracle/_ref/libopenpano_ref.so by oracle/Makefile.  Used to
+//   (1) pin the plain-C restatement in oracle/sift_oracle.c etc. (bit-exact, per stage),
+//   (2) generate the golden vectors under tests/golden/ (tests/golden/make_golden.py),
+//   (3) serve as the "reference" CPU baseline in bench.py when the .so travelled.
+// Nothing here is reference source: it only *calls* the reference API
+// (feature/feature.hh:42-57, feature/dog.hh, feature/extrema.hh, feature/orientation.hh,
+//  feature/sift.hh, feature/matcher.hh:31-51, lib/config.hh:24-85).
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <omp.h>
+
+#include "lib/config.hh"
+#include "lib/mat.h"
+#include "lib/imgproc.hh"
+#include "feature/feature.hh"
+#include "feature/dog.hh"
+#include "feature/extrema.hh"
+#include "feature/orientation.hh"
+#include "feature/sift.hh"
+#include "feature/matcher.hh"
+#include "feature/gaussian.hh"
+
+using namespace pano;
+using namespace config;
+
+namespace {
+
+struct ExtremaPub : public ExtremaDetector {
+	explicit ExtremaPub(const DOGSpace& d): ExtremaDetector(d) {}
+	using ExtremaDetector::get_local_raw_extrema;
+};
+
+struct SiftRun {
+	Mat32f resized;
+	std::unique_ptr<ScaleSpace> ss;
+	std::unique_ptr<DOGSpace> dog;
+	std::vector<std::vector<Coor>> raw;	// [octave*(nscale-3) + (scale-1)]
+	std::vector<SSPoint> refined, oriented;
+	std::vector<Descriptor> desc;
+};
+
+Mat32f wrap_rgb(const float* rgb, int h, int w) {
+	Mat32f m(h, w, 3);
+	memcpy(m.ptr(), rgb, sizeof(float) * (size_t)h * w * 3);
+	return m;
+}
+
+bool sspoint_less(const SSPoint& a, const SSPoint& b) {
+	if (a.pyr_id != b.pyr_id) return a.pyr_id < b.pyr_id;
+	if (a.scale_id != b.scale_id) return a.scale_id < b.scale_id;
+	if (a.coor.y != b.coor.y) return a.coor.y < b.coor.y;
+	if (a.coor.x != b.coor.x) return a.coor.x < b.coor.x;
+	if (a.real_coor.x != b.real_coor.x) return a.real_coor.x < b.real_coor.x;
+	return a.real_coor.y < b.real_coor.y;
+}
+
+}	// namespace
+
+extern "C" {
+
+// mirrors init_config() (main.cc:237-292): every key assigned from a float
+int ref_config_set(const char* key, float v) {
+	std::string k(key);
+#define CFG(x) if (k == #x) { x = v; return 0; }
+	CFG(CYLINDER) CFG(TRANS) CFG(ESTIMATE_CAMERA) CFG(ORDERED_INPUT) CFG(CROP) CFG(STRAIGHTEN)
+	CFG(FOCAL_LENGTH) CFG(MAX_OUTPUT_SIZE) CFG(LAZY_READ) CFG(SIFT_WORKING_SIZE) CFG(NUM_OCTAVE)
+	CFG(NUM_SCALE) CFG(SCALE_FACTOR) CFG(GAUSS_SIGMA) CFG(GAUSS_WINDOW_FACTOR)
+	CFG(JUDGE_EXTREMA_DIFF_THRES) CFG(CONTRAST_THRES) CFG(PRE_COLOR_THRES) CFG(EDGE_RATIO)
+	CFG(CALC_OFFSET_DEPTH) CFG(OFFSET_THRES) CFG(ORI_RADIUS) CFG(ORI_HIST_SMOOTH_COUNT)
+	CFG(DESC_HIST_SCALE_FACTOR) CFG(DESC_INT_FACTOR) CFG(MATCH_REJECT_NEXT_RATIO)
+	CFG(RANSAC_ITERATIONS) CFG(RANSAC_INLIER_THRES) CFG(INLIER_IN_MATCH_RATIO)
+	CFG(INLIER_IN_POINTS_RATIO) CFG(SLOPE_PLAIN) CFG(LM_LAMBDA) CFG(MULTIPASS_BA) CFG(MULTIBAND)
+#undef CFG
+	return -1;
+}
+
+void ref_set_threads(int n) { omp_set_num_threads(n); }
+
+// ---- staged SIFT run (body of SIFTDetector::do_detect_feature, feature.cc:31-47,
+//      with every intermediate kept) ----
+void* ref_sift_new(const float* rgb, int h, int w) {
+	SiftRun* r = new SiftRun;
+	Mat32f mat = wrap_rgb(rgb, h, w);
+	float ratio = SIFT_WORKING_SIZE * 2.0f / (mat.width() + mat.height());
+	r->resized = Mat32f(mat.rows() * ratio, mat.cols() * ratio, 3);
+	resize(mat, r->resized);
+	r->ss.reset(new ScaleSpace(r->resized, NUM_OCTAVE, NUM_SCALE));
+	r->dog.reset(new DOGSpace(*r->ss));
+	ExtremaPub ex(*r->dog);
+	for (int i = 0; i < NUM_OCTAVE; ++i)
+		for (int j = 1; j < NUM_SCALE - 2; ++j)
+			r->raw.emplace_back(ex.get_local_raw_extrema(i, j));
+	r->refined = ex.get_extrema();
+	// reference order is thread-timing dependent (extrema.cc:56) -> canonicalise
+	std::sort(r->refined.begin(), r->refined.end(), sspoint_less);
+	OrientationAssign ort(*r->dog, *r->ss, r->refined);
+	r->oriented = ort.work();
+	SIFT sift(*r->ss, r->oriented);
+	r->desc = sift.get_descriptor();
+	return r;
+}
+
+void ref_sift_free(void* hd) { delete (SiftRun*)hd; }
+
+void ref_sift_working_dims(void* hd, int* h, int* w) {
+	SiftRun* r = (SiftRun*)hd;
+	*h = r->resized.height(); *w = r->resized.width();
+}
+
+void ref_sift_octave_dims(void* hd, int oct, int* h, int* w) {
+	SiftRun* r = (SiftRun*)hd;
+	*h = r->ss->pyramids[oct].h; *w = r->ss->pyramids[oct].w;
+}
+
+// kind: 0 gaussian stack data[s] (s=0 is the grey base), 1 DoG[s], 2 mag[s], 3 ort[s], 4 working RGB
+int ref_sift_plane(void* hd, int kind, int oct, int s, float* out) {
+	SiftRun* r = (SiftRun*)hd;
+	const Mat32f* m = nullptr;
+	if (kind == 4) m = &r->resized;
+	else if (kind == 0) m = &r->ss->pyramids[oct].get(s);
+	else if (kind == 1) m = &r->dog->dogs[oct][s];
+	else if (kind == 2) m = &r->ss->pyramids[oct].get_mag(s);
+	else if (kind == 3) m = &r->ss->pyramids[oct].get_ort(s);
+	if (!m || m->rows() == 0) return -1;
+	memcpy(out, m->ptr(), sizeof(float) * (size_t)m->rows() * m->cols() * m->channels());
+	return 0;
+}
+
+int ref_sift_raw_count(void* hd, int oct, int s) {
+	SiftRun* r = (SiftRun*)hd;
+	return (int)r->raw[oct * (NUM_SCALE - 3) + (s - 1)].size();
+}
+void ref_sift_raw(void* hd, int oct, int s, int* xy) {
+	SiftRun* r = (SiftRun*)hd;
+	auto& v = r->raw[oct * (NUM_SCALE - 3) + (s - 1)];
+	for (size_t i = 0; i < v.size(); ++i) { xy[2 * i] = v[i].x; xy[2 * i + 1] = v[i].y; }
+}
+
+// which: 0 refined (after calc_kp_offset + edge test), 1 oriented
+int ref_sift_kp_count(void* hd, int which) {
+	SiftRun* r = (SiftRun*)hd;
+	return (int)(which ? r->oriented.size() : r->refined.size());
+}
+// ints: x, y, pyr_id, scale_id ; real: real_coor.x, real_coor.y ; fl: dir, scale_factor
+void ref_sift_kp(void* hd, int which, int* ints, double* real, float* fl) {
+	SiftRun* r = (SiftRun*)hd;
+	auto& v = which ? r->oriented : r->refined;
+	for (size_t i = 0; i < v.size(); ++i) {
+		ints[4 * i] = v[i].coor.x; ints[4 * i + 1] = v[i].coor.y;
+		ints[4 * i + 2] = v[i].pyr_id; ints[4 * i + 3] = v[i].scale_id;
+		real[2 * i] = v[i].real_coor.x; real[2 * i + 1] = v[i].real_coor.y;
+		fl[2 * i] = which ? v[i].dir : 0.f; fl[2 * i + 1] = v[i].scale_factor;
+	}
+}
+int ref_sift_desc_count(void* hd) { return (int)((SiftRun*)hd)->desc.size(); }
+void ref_sift_desc(void* hd, float* desc, double* coor) {
+	SiftRun* r = (SiftRun*)hd;
+	for (size_t i = 0; i < r->desc.size(); ++i) {
+		memcpy(desc + 128 * i, r->desc[i].descriptor.data(), 128 * sizeof(float));
+		coor[2 * i] = r->desc[i].coor.x; coor[2 * i + 1] = r->desc[i].coor.y;
+	}
+}
+
+// ---- the public entry point: FeatureDetector::detect_feature (feature.cc:20-28) ----
+// Two-phase: returns a handle holding the vector<Descriptor>.
+void* ref_detect_feature(const float* rgb, int h, int w) {
+	SIFTDetector det;
+	auto* v = new std::vector<Descriptor>(det.detect_feature(wrap_rgb(rgb, h, w)));
+	return v;
+}
+int ref_features_count(void* hd) { return (int)((std::vector<Descriptor>*)hd)->size(); }
+void ref_features_get(void* hd, float* desc, double* coor) {
+	auto& v = *(std::vector<Descriptor>*)hd;
+	for (size_t i = 0; i < v.size(); ++i) {
+		memcpy(desc + 128 * i, v[i].descriptor.data(), 128 * sizeof(float));
+		coor[2 * i] = v[i].coor.x; coor[2 * i + 1] = v[i].coor.y;
+	}
+}
+void ref_features_free(void* hd) { delete (std::vector<Descriptor>*)hd; }
+
+// body of StitcherBase::calc_feature() (stitcherbase.cc:14-25) minus ImageRef::load:
+// omp-parallel loop of detect_feature over n images of equal size. Returns total #descriptors.
+long ref_calc_feature_batch(const float* rgb, int n, int h, int w, int nthreads) {
+	long total = 0;
+	SIFTDetector det;
+	omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic) reduction(+:total)
+	for (int i = 0; i < n; ++i) {
+		auto v = det.detect_feature(wrap_rgb(rgb + (size_t)i * h * w * 3, h, w));
+		total += (long)v.size();
+	}
+	return total;
+}
+
+// ---- exact matcher: FeatureMatcher::match (matcher.cc:15-71) ----
+static std::vector<Descriptor> wrap_desc(const float* d, int n) {
+	std::vector<Descriptor> v(n);
+	for (int i = 0; i < n; ++i) v[i].descriptor.assign(d + 128 * (size_t)i, d + 128 * (size_t)(i + 1));
+	return v;
+}
+// out must hold 2*min(n1,n2) ints; returns #matches, pairs sorted by (first, second)
+int ref_match_exact(const float* d1, int n1, const float* d2, int n2, int* out) {
+	auto f1 = wrap_desc(d1, n1), f2 = wrap_desc(d2, n2);
+	FeatureMatcher m(f1, f2);
+	auto md = m.match();
+	std::sort(md.data.begin(), md.data.end());
+	for (size_t i = 0; i < md.data.size(); ++i) { out[2 * i] = md.data[i].first; out[2 * i + 1] = md.data[i].second; }
+	return md.size();
+}
+// PairWiseMatcher (FLANN kd-forest; approximate, non-deterministic: SURVEY F2/F3) over 2 images
+int ref_match_flann(const float* d1, int n1, const float* d2, int n2, int* out) {
+	std::vector<std::vector<Descriptor>> feats;
+	feats.emplace_back(wrap_desc(d1, n1));
+	feats.emplace_back(wrap_desc(d2, n2));
+	PairWiseMatcher pw(feats);
+	auto md = pw.match(0, 1);
+	std::sort(md.data.begin(), md.data.end());
+	for (size_t i = 0; i < md.data.size(); ++i) { out[2 * i] = md.data[i].first; out[2 * i + 1] = md.data[i].second; }
+	return md.size();
+}
+
+float ref_euclidean_sqr(const float* x, const float* y, int n, float thres) {
+	return pano::euclidean_sqr(x, y, n, thres);
+}
+
+// GaussCache weights (gaussian.cc:17-40); out needs >= kw floats, returns kw
+int ref_gauss_kernel(float sigma, float* out) {
+	GaussCache g(sigma);
+	for (int i = 0; i < g.kw; ++i) out[i] = g.kernel[i - g.kw / 2];
+	return g.kw;
+}
+
+}	// extern "C"

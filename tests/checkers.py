@@ -1,0 +1,265 @@
+"""ctypes bindings to the CPU checkers -- TEST INFRASTRUCTURE ONLY.
+
+``Oracle``  -> oracle/liboracle.so            (plain-C restatement, travels to the GPU box)
+``Ref``     -> oracle/_ref/libopenpano_ref.so (reference's own sources; may be absent)
+
+Both expose the same staged-SIFT interface so tests can compare them stage by stage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libopenpano_ref.so")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [
+        ("SIFT_WORKING_SIZE", C.c_int), ("NUM_OCTAVE", C.c_int), ("NUM_SCALE", C.c_int),
+        ("SCALE_FACTOR", C.c_float), ("GAUSS_SIGMA", C.c_float), ("GAUSS_WINDOW_FACTOR", C.c_int),
+        ("JUDGE_EXTREMA_DIFF_THRES", C.c_float), ("CONTRAST_THRES", C.c_float),
+        ("PRE_COLOR_THRES", C.c_float), ("EDGE_RATIO", C.c_float),
+        ("CALC_OFFSET_DEPTH", C.c_int), ("OFFSET_THRES", C.c_float),
+        ("ORI_RADIUS", C.c_float), ("ORI_HIST_SMOOTH_COUNT", C.c_int),
+        ("DESC_HIST_SCALE_FACTOR", C.c_int), ("DESC_INT_FACTOR", C.c_int),
+        ("MATCH_REJECT_NEXT_RATIO", C.c_float),
+    ]
+
+    @classmethod
+    def from_config(cls, cfg):
+        c = cls()
+        for name, _ in cls._fields_:
+            setattr(c, name, getattr(cfg, name))
+        return c
+
+
+class SiftStages:
+    """All intermediates of one staged SIFT run, copied to numpy."""
+
+    def __init__(self):
+        self.work = None          # working RGB (h, w, 3)
+        self.dims = []            # [(h, w)] per octave
+        self.gauss = {}           # (o, s) -> plane
+        self.dog = {}
+        self.mag = {}
+        self.ort = {}
+        self.raw = {}             # (o, s) -> (n, 2) int32 [x, y]
+        self.refined = None       # dict(ints (n,4), real (n,2), fl (n,2))
+        self.oriented = None
+        self.desc = None          # (K, 128) float32
+        self.coor = None          # (K, 2) float64 in [0,1)
+
+
+class _StagedBase:
+    prefix = ""
+
+    def _bind_staged(self, lib, with_cfg):
+        p = self.prefix
+        lead = [C.c_void_p] if with_cfg else []
+        getattr(lib, p + "sift_new").restype = C.c_void_p
+        getattr(lib, p + "sift_new").argtypes = lead + [_f32p, C.c_int, C.c_int]
+        getattr(lib, p + "sift_free").argtypes = [C.c_void_p]
+        for n in ("sift_working_dims",):
+            getattr(lib, p + n).argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        getattr(lib, p + "sift_octave_dims").argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        getattr(lib, p + "sift_plane").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]
+        getattr(lib, p + "sift_raw_count").argtypes = [C.c_void_p, C.c_int, C.c_int]
+        getattr(lib, p + "sift_raw").argtypes = [C.c_void_p, C.c_int, C.c_int, _i32p]
+        getattr(lib, p + "sift_kp_count").argtypes = [C.c_void_p, C.c_int]
+        getattr(lib, p + "sift_kp").argtypes = [C.c_void_p, C.c_int, _i32p, _f64p, _f32p]
+        getattr(lib, p + "sift_desc_count").argtypes = [C.c_void_p]
+        getattr(lib, p + "sift_desc").argtypes = [C.c_void_p, _f32p, _f64p]
+
+    def _collect(self, lib, hd, cfg, planes=True):
+        p = self.prefix
+        st = SiftStages()
+        h, w = C.c_int(), C.c_int()
+        getattr(lib, p + "sift_working_dims")(hd, C.byref(h), C.byref(w))
+        st.work = np.empty((h.value, w.value, 3), np.float32)
+        getattr(lib, p + "sift_plane")(hd, 4, 0, 0, st.work.reshape(-1))
+        for o in range(cfg.NUM_OCTAVE):
+            getattr(lib, p + "sift_octave_dims")(hd, o, C.byref(h), C.byref(w))
+            st.dims.append((h.value, w.value))
+            if planes:
+                for s in range(cfg.NUM_SCALE):
+                    for kind, dst in ((0, st.gauss), (1, st.dog), (2, st.mag), (3, st.ort)):
+                        if kind == 1 and s >= cfg.NUM_SCALE - 1:
+                            continue
+                        if kind in (2, 3) and s == 0:
+                            continue
+                        buf = np.empty((h.value, w.value), np.float32)
+                        rc = getattr(lib, p + "sift_plane")(hd, kind, o, s, buf.reshape(-1))
+                        assert rc == 0, (kind, o, s)
+                        dst[(o, s)] = buf
+            for s in range(1, cfg.NUM_SCALE - 2):
+                n = getattr(lib, p + "sift_raw_count")(hd, o, s)
+                xy = np.empty((n, 2), np.int32)
+                if n:
+                    getattr(lib, p + "sift_raw")(hd, o, s, xy.reshape(-1))
+                st.raw[(o, s)] = xy
+        for which, name in ((0, "refined"), (1, "oriented")):
+            n = getattr(lib, p + "sift_kp_count")(hd, which)
+            ints = np.empty((n, 4), np.int32); real = np.empty((n, 2), np.float64); fl = np.empty((n, 2), np.float32)
+            if n:
+                getattr(lib, p + "sift_kp")(hd, which, ints.reshape(-1), real.reshape(-1), fl.reshape(-1))
+            setattr(st, name, dict(ints=ints, real=real, fl=fl))
+        k = getattr(lib, p + "sift_desc_count")(hd)
+        st.desc = np.empty((k, 128), np.float32); st.coor = np.empty((k, 2), np.float64)
+        if k:
+            getattr(lib, p + "sift_desc")(hd, st.desc.reshape(-1), st.coor.reshape(-1))
+        return st
+
+
+class Oracle(_StagedBase):
+    prefix = "orc_"
+
+    def __init__(self, cfg):
+        build_oracle()
+        self.cfg = cfg
+        self.ccfg = OrcCfg.from_config(cfg)
+        lib = self.lib = C.CDLL(ORACLE_SO)
+        self._bind_staged(lib, with_cfg=True)
+        lib.orc_detect_feature.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_double))]
+        lib.orc_free.argtypes = [C.c_void_p]
+        lib.orc_calc_feature_batch.restype = C.c_long
+        lib.orc_calc_feature_batch.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_gauss_kernel.argtypes = [C.c_void_p, C.c_float, _f32p]
+        for n in ("orc_expf_twin", "orc_cosf_twin", "orc_sinf_twin"):
+            getattr(lib, n).restype = C.c_float; getattr(lib, n).argtypes = [C.c_float]
+        lib.orc_hypotf_twin.restype = C.c_float; lib.orc_hypotf_twin.argtypes = [C.c_float, C.c_float]
+        lib.orc_euclidean_sqr.restype = C.c_float
+        lib.orc_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
+        lib.orc_match_exact.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, _i32p]
+
+    def _cp(self):
+        return C.byref(self.ccfg)
+
+    def sift_stages(self, img, planes=True):
+        img = np.ascontiguousarray(img, np.float32)
+        hd = self.lib.orc_sift_new(self._cp(), img.reshape(-1), img.shape[0], img.shape[1])
+        try:
+            return self._collect(self.lib, hd, self.cfg, planes)
+        finally:
+            self.lib.orc_sift_free(hd)
+
+    def detect_feature(self, img):
+        """-> (desc (K,128) f32, coor (K,2) f64 centred image coords), canonical order."""
+        img = np.ascontiguousarray(img, np.float32)
+        d = C.POINTER(C.c_float)(); c = C.POINTER(C.c_double)()
+        k = self.lib.orc_detect_feature(self._cp(), img.reshape(-1), img.shape[0], img.shape[1], C.byref(d), C.byref(c))
+        desc = np.ctypeslib.as_array(d, (max(k, 1), 128))[:k].copy()
+        coor = np.ctypeslib.as_array(c, (max(k, 1), 2))[:k].copy()
+        self.lib.orc_free(d); self.lib.orc_free(c)
+        return desc, coor
+
+    def calc_feature_batch(self, imgs, nthreads):
+        a = np.ascontiguousarray(np.stack(imgs), np.float32)
+        return self.lib.orc_calc_feature_batch(self._cp(), a.reshape(-1), a.shape[0], a.shape[1], a.shape[2], nthreads)
+
+    def gauss_kernel(self, sigma):
+        buf = np.zeros(128, np.float32)
+        kw = self.lib.orc_gauss_kernel(self._cp(), np.float32(sigma), buf)
+        return buf[:kw].copy()
+
+    def match_exact(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+        out = np.empty((max(1, min(len(d1), len(d2))), 2), np.int32)
+        n = self.lib.orc_match_exact(self._cp(), d1.reshape(-1), len(d1), d2.reshape(-1), len(d2), out.reshape(-1))
+        return out[:n].copy()
+
+    def euclidean_sqr(self, x, y, thres=np.float32(3.4e38)):
+        return self.lib.orc_euclidean_sqr(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), len(x), thres)
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+class Ref(_StagedBase):
+    prefix = "ref_"
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        lib = self.lib = C.CDLL(REF_SO)
+        lib.ref_config_set.argtypes = [C.c_char_p, C.c_float]
+        for k, v in cfg.raw_items():
+            rc = lib.ref_config_set(k.encode(), float(v))
+            assert rc == 0, k
+        lib.ref_set_threads.argtypes = [C.c_int]
+        lib.ref_set_threads(1)
+        self._bind_staged(lib, with_cfg=False)
+        lib.ref_detect_feature.restype = C.c_void_p
+        lib.ref_detect_feature.argtypes = [_f32p, C.c_int, C.c_int]
+        lib.ref_features_count.argtypes = [C.c_void_p]
+        lib.ref_features_get.argtypes = [C.c_void_p, _f32p, _f64p]
+        lib.ref_features_free.argtypes = [C.c_void_p]
+        lib.ref_calc_feature_batch.restype = C.c_long
+        lib.ref_calc_feature_batch.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.ref_match_exact.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _i32p]
+        lib.ref_match_flann.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _i32p]
+        lib.ref_euclidean_sqr.restype = C.c_float
+        lib.ref_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
+        lib.ref_gauss_kernel.argtypes = [C.c_float, _f32p]
+
+    def sift_stages(self, img, planes=True):
+        img = np.ascontiguousarray(img, np.float32)
+        hd = self.lib.ref_sift_new(img.reshape(-1), img.shape[0], img.shape[1])
+        try:
+            return self._collect(self.lib, hd, self.cfg, planes)
+        finally:
+            self.lib.ref_sift_free(hd)
+
+    def detect_feature(self, img):
+        img = np.ascontiguousarray(img, np.float32)
+        hd = self.lib.ref_detect_feature(img.reshape(-1), img.shape[0], img.shape[1])
+        k = self.lib.ref_features_count(hd)
+        desc = np.empty((k, 128), np.float32); coor = np.empty((k, 2), np.float64)
+        if k:
+            self.lib.ref_features_get(hd, desc.reshape(-1), coor.reshape(-1))
+        self.lib.ref_features_free(hd)
+        return desc, coor
+
+    def calc_feature_batch(self, imgs, nthreads):
+        a = np.ascontiguousarray(np.stack(imgs), np.float32)
+        return self.lib.ref_calc_feature_batch(a.reshape(-1), a.shape[0], a.shape[1], a.shape[2], nthreads)
+
+    def gauss_kernel(self, sigma):
+        buf = np.zeros(128, np.float32)
+        kw = self.lib.ref_gauss_kernel(np.float32(sigma), buf)
+        return buf[:kw].copy()
+
+    def match_exact(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+        out = np.empty((max(1, min(len(d1), len(d2))), 2), np.int32)
+        n = self.lib.ref_match_exact(d1.reshape(-1), len(d1), d2.reshape(-1), len(d2), out.reshape(-1))
+        return out[:n].copy()
+
+    def match_flann(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+        out = np.empty((max(1, min(len(d1), len(d2))), 2), np.int32)
+        n = self.lib.ref_match_flann(d1.reshape(-1), len(d1), d2.reshape(-1), len(d2), out.reshape(-1))
+        return out[:n].copy()
+
+    def euclidean_sqr(self, x, y, thres=np.float32(3.4e38)):
+        return self.lib.ref_euclidean_sqr(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), len(x), thres)
+
+
+def sort_features(desc, coor):
+    """Canonical order for comparing detect_feature outputs (the reference's is nondeterministic)."""
+    key = np.lexsort((desc[:, 0], coor[:, 0], coor[:, 1])) if len(desc) else np.arange(0)
+    return desc[key], coor[key]

@@ -1,0 +1,80 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own code (oracle/_ref).
+
+Run in the build container (needs /root/reference to have built oracle/_ref):
+    python tests/golden/make_golden.py
+The reference ships no golden vectors, so these fixtures -- outputs of the
+unmodified reference sources on small seeded inputs -- are what pins the C oracle
+(tests/test_oracle_golden.py, runs anywhere) and, through it, the HIP path.
+
+Each sift_*.npz holds: the uint8 input, octave dims, per-(octave,scale) raw-extrema counts,
+refined/oriented keypoints, descriptors, and CRC32s of every working/DoG/mag/ort plane.
+match_*.npz holds two descriptor sets and the exact matcher's pair list.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from openpano_amd.config import PanoConfig  # noqa: E402
+from openpano_amd import synth  # noqa: E402
+from checkers import Ref  # noqa: E402
+
+
+def u8_to_f32(u8):
+    # read_png (lib/imgio.cc:43-60): (float)byte / 255.0 evaluated in double
+    return (u8.astype(np.float64) / 255.0).astype(np.float32)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def sift_case(ref, name, img_u8):
+    st = ref.sift_stages(u8_to_f32(img_u8))
+    desc, coor = ref.detect_feature(u8_to_f32(img_u8))
+    out = dict(
+        img=img_u8, dims=np.array(st.dims, np.int32), work_crc=np.uint32(crc(st.work)),
+        raw_counts=np.array([[len(st.raw[(o, s)]) for s in range(1, 5)] for o in range(4)], np.int32),
+        refined_ints=st.refined["ints"], refined_real=st.refined["real"], refined_sf=st.refined["fl"][:, 1],
+        oriented_ints=st.oriented["ints"], oriented_dir=st.oriented["fl"][:, 0],
+        desc=st.desc, coor=st.coor, n_detect=np.int32(len(desc)),
+    )
+    for kind in ("dog", "mag", "ort"):
+        planes = getattr(st, kind)
+        keys = sorted(planes)
+        out[kind + "_keys"] = np.array(keys, np.int32)
+        out[kind + "_crc"] = np.array([crc(planes[k]) for k in keys], np.uint32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, img_u8.shape, "raw", out["raw_counts"].sum(), "refined", len(st.refined["ints"]), "desc", len(st.desc))
+    return st
+
+
+def main():
+    cfg = PanoConfig()
+    ref = Ref(cfg)
+    # three small views: landscape, portrait-ish odd sizes, and a tiny one that is up-scaled 4x
+    w1 = synth.make_world(101, 300, 520, work_scale=1600.0 / (240 + 320), density=900.0)
+    a = (synth.cut_view(w1, 20, 20, 240, 320, 1) * 255 + 0.5).astype(np.uint8)
+    b = (synth.cut_view(w1, 30, 150, 240, 320, 2) * 255 + 0.5).astype(np.uint8)
+    w2 = synth.make_world(202, 330, 260, work_scale=1600.0 / (301 + 227), density=1500.0)
+    c = (synth.cut_view(w2, 10, 10, 301, 227, 3) * 255 + 0.5).astype(np.uint8)
+    sa = sift_case(ref, "sift_a_240x320", a)
+    sb = sift_case(ref, "sift_b_240x320", b)
+    sift_case(ref, "sift_c_301x227", c)
+    # a down-scaled, finely textured view: exercises offset iterations, contrast and edge rejections
+    w3 = synth.make_world(303, 540, 740, work_scale=1600.0 / (500 + 700), density=250.0)
+    d = (synth.cut_view(w3, 20, 20, 500, 700, 4) * 255 + 0.5).astype(np.uint8)
+    sift_case(ref, "sift_d_500x700", d)
+    pairs = ref.match_exact(sa.desc, sb.desc)
+    np.savez_compressed(os.path.join(HERE, "match_ab.npz"), pairs=pairs,
+                        n1=np.int32(len(sa.desc)), n2=np.int32(len(sb.desc)))
+    print("match_ab", len(sa.desc), len(sb.desc), "->", len(pairs))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""CPU: the C oracle (oracle/liboracle.so) against the committed golden vectors, which are
+outputs of the reference's own sources (tests/golden/make_golden.py).  Bit-exact everywhere."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sift_*.npz")))
+
+
+def u8_to_f32(u8):
+    return (u8.astype(np.float64) / 255.0).astype(np.float32)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_sift_stages_match_golden(oracle, path):
+    g = np.load(path)
+    st = oracle.sift_stages(u8_to_f32(g["img"]))
+    assert np.array_equal(np.array(st.dims, np.int32), g["dims"])
+    assert crc(st.work) == int(g["work_crc"])
+    for kind in ("dog", "mag", "ort"):
+        planes = getattr(st, kind)
+        for key, want in zip(g[kind + "_keys"], g[kind + "_crc"]):
+            assert crc(planes[tuple(int(v) for v in key)]) == int(want), (kind, key)
+    raw = np.array([[len(st.raw[(o, s)]) for s in range(1, 5)] for o in range(4)], np.int32)
+    assert np.array_equal(raw, g["raw_counts"])
+    assert np.array_equal(st.refined["ints"], g["refined_ints"])
+    assert np.array_equal(st.refined["real"], g["refined_real"])
+    assert np.array_equal(st.refined["fl"][:, 1], g["refined_sf"])
+    assert np.array_equal(st.oriented["ints"], g["oriented_ints"])
+    assert np.array_equal(st.oriented["fl"][:, 0], g["oriented_dir"])
+    assert np.array_equal(st.desc, g["desc"])
+    assert np.array_equal(st.coor, g["coor"])
+    # all RootSIFT descriptors have L2 norm DESC_INT_FACTOR (sift.cc:40-43)
+    assert np.allclose(np.linalg.norm(st.desc.astype(np.float64), axis=1), 512.0, rtol=1e-5)
+
+
+def test_detect_feature_coordinates(oracle):
+    g = np.load(CASES[0])
+    img = u8_to_f32(g["img"])
+    desc, coor = oracle.detect_feature(img)
+    assert len(desc) == int(g["n_detect"])
+    assert np.array_equal(desc, g["desc"])
+    # feature.cc:23-26: (c - 0.5) * {w, h}
+    assert np.array_equal(coor[:, 0], (g["coor"][:, 0] - 0.5) * img.shape[1])
+    assert np.array_equal(coor[:, 1], (g["coor"][:, 1] - 0.5) * img.shape[0])
+
+
+def test_exact_matcher_golden(oracle):
+    a = np.load(os.path.join(HERE, "golden", "sift_a_240x320.npz"))
+    b = np.load(os.path.join(HERE, "golden", "sift_b_240x320.npz"))
+    m = np.load(os.path.join(HERE, "golden", "match_ab.npz"))
+    pairs = oracle.match_exact(a["desc"], b["desc"])
+    assert np.array_equal(pairs, m["pairs"])
+    # swapping the arguments swaps the pair columns (matcher.cc:21-28,68-69)
+    rp = oracle.match_exact(b["desc"], a["desc"])
+    assert sorted(map(tuple, rp[:, ::-1])) == sorted(map(tuple, pairs))
+
+
+def test_matcher_edge_cases(oracle):
+    a = np.load(os.path.join(HERE, "golden", "sift_a_240x320.npz"))["desc"]
+    assert len(oracle.match_exact(a[:0], a)) == 0          # empty set
+    # one-vs-one: min = 0, next_min stays FLT_MAX, 0 > 0.64*FLT_MAX is false -> accepted
+    assert np.array_equal(oracle.match_exact(a[:1], a[:1]), [[0, 0]])
+    # identical sets: every descriptor's best is itself at distance 0 -> accepted (0 > 0.64*d is false)
+    p = oracle.match_exact(a[:50], a[:50])
+    assert np.array_equal(p, np.stack([np.arange(50), np.arange(50)], 1))
