@@ -1,0 +1,153 @@
+/* include/openpano_hip.h -- C-ABI of libopenpano_hip.so, the MI355X (gfx950) implementation of
+ * OpenPano's data-parallel hot path.
+ *
+ * The reference has no FFI: its seam is the C++ class surface.  Each entry point below names
+ * the reference interface it stands in for (file:line under /root/reference/src); the C++
+ * adapters in openpano_amd/csrc/adapters/ re-expose the reference's own class names
+ * (FeatureDetector::detect_feature, PairWiseMatcher::match, ...) on top of these calls, and
+ * INTEGRATION.md shows the binding a maintainer would add to the reference tree.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary;
+ *   - every function returns OP_OK (0) or a negative op_status; op_last_error() gives the
+ *     message of the calling thread's last failure (the adapters turn it into the reference's
+ *     error_exit(), lib/debugutils.cc:57-60); no exception crosses the ABI;
+ *   - images are the reference's Mat32f layout (lib/mat.h:8-57): row-major H x W x 3 fp32 in
+ *     [0,1]; a pointer may be host or device memory (flag on_device);
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails.
+ */
+#ifndef OPENPANO_HIP_H
+#define OPENPANO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	OP_OK = 0,
+	OP_ERR_INVALID = -1,      /* bad argument */
+	OP_ERR_HIP = -2,          /* a HIP runtime call failed (message has the hipError string) */
+	OP_ERR_CAPACITY = -3,     /* a device-side work list overflowed its capacity */
+	OP_ERR_UNSUPPORTED = -4,  /* configuration outside what the kernels implement */
+	OP_ERR_NO_FEATURE = -5    /* an image produced zero features (stitcherbase.cc:20-21) */
+} op_status;
+
+const char* op_last_error(void);
+/* library/ABI version, bumped on incompatible change */
+int op_abi_version(void);
+
+/* ---- configuration: POD snapshot of namespace config (lib/config.hh:24-85), taken by the
+ * adapters at every call because the CLI fills the globals after static init (main.cc:237-292) */
+typedef struct op_config {
+	/* SIFT (config.cfg:19-41) */
+	int SIFT_WORKING_SIZE, NUM_OCTAVE, NUM_SCALE;
+	float SCALE_FACTOR, GAUSS_SIGMA;
+	int GAUSS_WINDOW_FACTOR;
+	float JUDGE_EXTREMA_DIFF_THRES, CONTRAST_THRES, PRE_COLOR_THRES, EDGE_RATIO;
+	int CALC_OFFSET_DEPTH;
+	float OFFSET_THRES;
+	float ORI_RADIUS;
+	int ORI_HIST_SMOOTH_COUNT;
+	int DESC_HIST_SCALE_FACTOR, DESC_INT_FACTOR;
+	/* matching / RANSAC (config.cfg:45-54) */
+	float MATCH_REJECT_NEXT_RATIO;
+	int RANSAC_ITERATIONS;
+	double RANSAC_INLIER_THRES;
+	float INLIER_IN_MATCH_RATIO, INLIER_IN_POINTS_RATIO;
+	/* modes that change kernel behaviour (config.cfg:2-10,69) */
+	int CYLINDER, TRANS, ESTIMATE_CAMERA, ORDERED_INPUT, LAZY_READ, MULTIBAND;
+	int MAX_OUTPUT_SIZE;
+	float FOCAL_LENGTH;
+} op_config;
+/* shipped defaults, src/config.cfg */
+void op_config_default(op_config* cfg);
+
+/* ---- context: one per (process, device); owns the stream and the HBM workspaces.
+ * stream = NULL creates a private hipStream; otherwise the caller's hipStream_t is used (e.g.
+ * torch.cuda.current_stream().cuda_stream) and all work is ordered on it. Thread-compatible:
+ * concurrent calls need distinct contexts (StitcherBase::calc_feature's omp loop,
+ * stitcherbase.cc:14, maps to ONE batched call instead). */
+typedef struct op_ctx op_ctx;
+int op_ctx_create(int device, void* hip_stream, op_ctx** out);
+void op_ctx_destroy(op_ctx* ctx);
+int op_ctx_sync(op_ctx* ctx);
+
+typedef struct op_image {
+	const float* data;   /* H x W x 3 fp32 */
+	int h, w;
+	int on_device;       /* 0: host pointer (copied H2D inside the call), 1: device pointer */
+} op_image;
+
+/* =====================================================================================
+ * SIFT  -- replaces FeatureDetector::detect_feature / SIFTDetector::do_detect_feature
+ * (feature/feature.hh:50-57, feature/feature.cc:20-47) looped over images by
+ * StitcherBase::calc_feature (stitch/stitcherbase.cc:9-27).
+ * One call extracts the features of n images; results stay resident in HBM inside an
+ * op_features object so that the matcher reads them without a second H2D pass.
+ * Output order per image is canonical: sorted by (octave, scale, y, x, real_x, real_y) of the
+ * refined keypoint, then orientation-peak order (the reference's order is thread-timing
+ * dependent, feature/extrema.cc:56).
+ * ===================================================================================== */
+typedef struct op_features op_features;
+int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n, op_features** out);
+int op_features_num_images(const op_features* f);
+/* number of descriptors of image i (K_i) and the exclusive prefix offset of its first row */
+int op_features_count(const op_features* f, int i);
+int64_t op_features_offset(const op_features* f, int i);
+int64_t op_features_total(const op_features* f);
+/* device-resident flat buffers: desc = total x 128 fp32, coor = total x 2 fp64
+ * (coordinates relative to the image centre in original-image pixels, feature.cc:23-26) */
+const float* op_features_desc_device(const op_features* f);
+const double* op_features_coor_device(const op_features* f);
+/* D2H copy of image i's K_i x 128 descriptors and K_i x 2 coordinates (either may be NULL) */
+int op_features_copy(op_ctx* ctx, const op_features* f, int i, float* desc, double* coor);
+/* build an op_features from host arrays (debug commands / tests: match without SIFT) */
+int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* const* coor,
+		const int* counts, int n, op_features** out);
+void op_features_free(op_features* f);
+
+/* Staged single-image run keeping every intermediate (the debug commands raw_extrema /
+ * keypoint / orientation of main.cc:41-81 and the per-stage parity tests).
+ * plane kinds: 1 DoG[s] (s in 0..nscale-2), 2 mag[s], 3 ort[s] (s in 1..nscale-3),
+ *              4 working RGB, 5 grey octave base. */
+typedef struct op_sift_dump op_sift_dump;
+int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_sift_dump** out);
+void op_sift_dump_free(op_sift_dump* d);
+int op_sift_dump_working_dims(const op_sift_dump* d, int* h, int* w);
+int op_sift_dump_octave_dims(const op_sift_dump* d, int oct, int* h, int* w);
+int op_sift_dump_plane(op_ctx* ctx, const op_sift_dump* d, int kind, int oct, int s, float* out);
+int op_sift_dump_raw_count(const op_sift_dump* d, int oct, int s);
+int op_sift_dump_raw(const op_sift_dump* d, int oct, int s, int* xy);       /* sorted (y, x) */
+/* which: 0 refined, 1 oriented; ints = x,y,octave,scale; real = real_coor; fl = dir, scale_factor */
+int op_sift_dump_kp_count(const op_sift_dump* d, int which);
+int op_sift_dump_kp(const op_sift_dump* d, int which, int* ints, double* real, float* fl);
+int op_sift_dump_desc(const op_sift_dump* d, float* desc, double* coor);    /* coor in [0,1) */
+
+/* device math twins of glibc expf/cosf/sinf/hypotf and of fast_atan (feature/dog.cc:22-37),
+ * evaluated on the GPU over n host values (tests: device == reference libm, bit for bit).
+ * which: 0 expf(x), 1 cosf(x), 2 sinf(x), 3 hypotf(x,y), 4 fast_atan(y,x)+pi */
+int op_debug_math(op_ctx* ctx, int which, const float* x, const float* y, int n, float* out);
+
+/* =====================================================================================
+ * MATCH -- replaces PairWiseMatcher (feature/matcher.hh:40-67, matcher.cc:73-135) as used by
+ * Stitcher::pairwise_match / linear_pairwise_match (stitch/stitcher.cc:96-136), with the
+ * semantics of the reference's exact matcher FeatureMatcher::match (matcher.cc:15-71): 2-NN
+ * ratio test from the smaller set, then the reverse test.  All requested pairs are
+ * matched in one launch series; fp32 MFMA tiles rank candidates, an exact re-score in the
+ * reference's summation order (feature/dist.cc:22-57) decides.
+ * ===================================================================================== */
+typedef struct op_matches op_matches;
+/* pairs: npairs x 2 image indices (i, j) into f */
+int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f,
+		const int* pairs, int npairs, op_matches** out);
+int op_matches_count(const op_matches* m, int p);
+/* pairs of <idx in image i, idx in image j> sorted by (first, second) (MatchData, matcher.hh:14-25) */
+int op_matches_copy(const op_matches* m, int p, int* idx_pairs);
+int64_t op_matches_total(const op_matches* m);
+void op_matches_free(op_matches* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENPANO_HIP_H */

@@ -1,0 +1,82 @@
+// capi.hip -- context, errors, configuration defaults of the C-ABI (include/openpano_hip.h)
+#include "internal.hpp"
+#include <cstring>
+
+static thread_local std::string g_last_error;
+void op_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" {
+
+const char* op_last_error(void) { return g_last_error.c_str(); }
+int op_abi_version(void) { return 1; }
+
+void op_config_default(op_config* c) {
+	// src/config.cfg (every literal goes through a float, lib/config.cc:19-26)
+	memset(c, 0, sizeof(*c));
+	c->SIFT_WORKING_SIZE = 800; c->NUM_OCTAVE = 4; c->NUM_SCALE = 7;
+	c->SCALE_FACTOR = 1.4142135623f; c->GAUSS_SIGMA = 1.4142135623f; c->GAUSS_WINDOW_FACTOR = 6;
+	c->JUDGE_EXTREMA_DIFF_THRES = 2e-3f; c->CONTRAST_THRES = 4e-2f; c->PRE_COLOR_THRES = 5e-2f;
+	c->EDGE_RATIO = 6.f; c->CALC_OFFSET_DEPTH = 4; c->OFFSET_THRES = 0.5f;
+	c->ORI_RADIUS = 4.5f; c->ORI_HIST_SMOOTH_COUNT = 2;
+	c->DESC_HIST_SCALE_FACTOR = 3; c->DESC_INT_FACTOR = 512;
+	c->MATCH_REJECT_NEXT_RATIO = 0.8f;
+	c->RANSAC_ITERATIONS = 1500; c->RANSAC_INLIER_THRES = (double)3.5f;
+	c->INLIER_IN_MATCH_RATIO = 0.1f; c->INLIER_IN_POINTS_RATIO = 0.04f;
+	c->CYLINDER = 0; c->TRANS = 0; c->ESTIMATE_CAMERA = 1; c->ORDERED_INPUT = 0; c->LAZY_READ = 1;
+	c->MULTIBAND = 0; c->MAX_OUTPUT_SIZE = 8000; c->FOCAL_LENGTH = 37.f;
+}
+
+int op_ctx_create(int device, void* hip_stream, op_ctx** out) {
+	if (!out) OP_FAIL(OP_ERR_INVALID, "op_ctx_create: out is NULL");
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		OP_FAIL(OP_ERR_HIP, std::string("op_ctx_create: no HIP device available (") + hipGetErrorString(e) +
+				"); libopenpano_hip has no CPU fallback");
+	if (device < 0 || device >= ndev) OP_FAIL(OP_ERR_INVALID, "op_ctx_create: bad device index");
+	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+	if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+		OP_FAIL(OP_ERR_UNSUPPORTED, std::string("op_ctx_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+	op_ctx* c = new op_ctx;
+	c->device = device;
+	if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
+	*out = c;
+	return OP_OK;
+}
+
+void op_ctx_destroy(op_ctx* c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	hipStreamSynchronize(c->stream);
+	op_ctx_release_workspace(c);
+	if (c->owns_stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int op_ctx_sync(op_ctx* c) {
+	if (!c) OP_FAIL(OP_ERR_INVALID, "op_ctx_sync: NULL context");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return OP_OK;
+}
+
+int op_debug_math(op_ctx* c, int which, const float* x, const float* y, int n, float* out) {
+	if (!c || !x || !out || n < 0 || which < 0 || which > 4) OP_FAIL(OP_ERR_INVALID, "op_debug_math: bad argument");
+	if (n == 0) return OP_OK;
+	HIPCHK(hipSetDevice(c->device));
+	float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+	HIPCHK(hipMalloc(&dx, sizeof(float) * n));
+	HIPCHK(hipMalloc(&dy, sizeof(float) * n));
+	HIPCHK(hipMalloc(&dout, sizeof(float) * n));
+	HIPCHK(hipMemcpyAsync(dx, x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(dy, y ? y : x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(launch_debug_math(which, dx, dy, n, dout, c->stream));
+	HIPCHK(hipMemcpyAsync(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	hipFree(dx); hipFree(dy); hipFree(dout);
+	return OP_OK;
+}
+
+}	// extern "C"

@@ -1,0 +1,97 @@
+// internal.hpp -- shared host/device declarations of libopenpano_hip.so (not part of the ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "openpano_hip.h"
+
+#define OP_MAX_OCT 8
+#define OP_MAX_SCALE 12      // NUM_SCALE <= 12
+#define OP_MAX_KCENTER 15    // Gaussian kernels up to 31 taps
+
+void op_set_error(const std::string& msg);
+struct op_ctx;
+void op_ctx_release_workspace(op_ctx* c);
+#define OP_FAIL(code, msg) do { op_set_error(msg); return (code); } while (0)
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return OP_ERR_HIP; } } while (0)
+
+struct op_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool owns_stream = false;
+};
+
+// ---------------------------------------------------------------------------------------
+// HBM layout of one image's scale space ("image workspace", ws_stride floats per image):
+//   for each octave o:  [grey][DoG 0 .. ns-2][mag 1 .. ns-3][ort 1 .. ns-3]   each h_o*w_o fp32,
+// row-major, octave blocks back to back.  The six Gaussian planes of the reference
+// (feature/dog.cc:53-57) never touch HBM: they live in LDS inside the pyramid kernel.
+// ---------------------------------------------------------------------------------------
+struct OctDesc {
+	int h, w;
+	int tiles_x, tiles_y, tile_begin;   // pyramid-kernel tiling
+	long long off;                      // float offset of the octave block in the image workspace
+	long long plane;                    // h*w
+};
+
+struct SiftPlan {
+	int n;                      // images in the batch (all sh x sw)
+	int sh, sw;                 // source size
+	int wh, ww;                 // working size (feature.cc:33-35)
+	int noct, nscale;
+	OctDesc oct[OP_MAX_OCT];
+	int total_tiles;
+	long long ws_stride;        // floats per image workspace
+	float* ws;
+	float* work;                // n x wh x ww x 3
+	const float* const* srcs;   // device array of n source pointers (device memory)
+	// Gaussian bank (feature/gaussian.cc:17-40): kern[s][center + k], s = 1..nscale-1
+	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
+	int kcenter[OP_MAX_SCALE];
+	int halo;                   // max kcenter
+	// thresholds
+	float pre_color_thres, judge_thres, contrast_thres, edge_ratio, offset_thres;
+	int calc_offset_depth;
+	float gauss_sigma, scale_factor, ori_radius;
+	int ori_smooth, desc_scale_factor, desc_int_factor;
+};
+
+__host__ __device__ inline long long plane_off_grey(const OctDesc& o) { return o.off; }
+__host__ __device__ inline long long plane_off_dog(const OctDesc& o, int s) { return o.off + (1 + s) * o.plane; }
+__host__ __device__ inline long long plane_off_mag(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (s - 1)) * o.plane; }
+__host__ __device__ inline long long plane_off_ort(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (ns - 3) + (s - 1)) * o.plane; }
+__host__ __device__ inline int planes_per_octave(int ns) { return 1 + (ns - 1) + 2 * (ns - 3); }
+
+// a scale-space point (feature/feature.hh:33-39), 48 bytes
+struct KeyPoint {
+	int x, y, oct, scale;
+	double rx, ry;          // real_coor in [0,1)
+	float dir, sf;          // dir, scale_factor
+	int src;                // index of the raw candidate / refined parent
+	int pad;
+};
+
+#define OP_PYR_TW 64
+#define OP_PYR_TH 32
+
+// ---- kernel launchers (each returns hipGetLastError of its launch) ----
+hipError_t launch_resize_to_work(const SiftPlan& p, hipStream_t st);
+hipError_t launch_octave_grey(const SiftPlan& p, hipStream_t st);
+hipError_t launch_pyramid(const SiftPlan& p, hipStream_t st);
+hipError_t launch_extrema_scan(const SiftPlan& p, int* raw /* n x cap x 4 */, int* raw_count /* n */, int cap, hipStream_t st);
+hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap,
+		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
+hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
+		KeyPoint* out, hipStream_t st);
+hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+		float* dirs /* n x cap x 36 */, int* ndirs /* n x cap */, hipStream_t st);
+hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+		const float* dirs, const int* ndirs, const long long* img_offset /* n+1, device */,
+		KeyPoint* oriented, hipStream_t st);
+hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
+		int* per_image /* n */, hipStream_t st);
+hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset /* n+1 device */,
+		long long total, float* desc, double* coor, hipStream_t st);
+hipError_t launch_debug_math(int which, const float* x, const float* y, int n, float* out, hipStream_t st);

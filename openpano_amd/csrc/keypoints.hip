@@ -1,0 +1,433 @@
+// keypoints.hip -- extrema scan, sub-pixel refinement, canonical ordering, orientation.
+//
+// Replaces ExtremaDetector::get_extrema and helpers (feature/extrema.cc:36-216) and
+// OrientationAssign (feature/orientation.cc:22-100) for a whole batch per launch.
+// Built with -ffp-contract=off; fp types and evaluation order follow the reference line by line
+// so that every accept/reject decision and every emitted number is identical to the CPU path.
+#include "internal.hpp"
+#include "devmath.hpp"
+
+namespace {
+
+__device__ __forceinline__ const float* dog_plane(const SiftPlan& p, int img, int o, int s) {
+	return p.ws + (long long)img * p.ws_stride + plane_off_dog(p.oct[o], s);
+}
+
+// ---- extrema scan (feature/extrema.cc:170-216): thread per pixel, loops the scanned layers ----
+__global__ void __launch_bounds__(256) k_extrema_scan(SiftPlan p, int* raw, int* raw_count, int cap) {
+	const int img = blockIdx.z, o = blockIdx.y;
+	const OctDesc od = p.oct[o];
+	const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (idx >= od.plane) return;
+	const int r = (int)(idx / od.w), c = (int)(idx % od.w);
+	if (r < 1 || r > od.h - 2 || c < 1 || c > od.w - 2) return;     // :212
+	const int w = od.w;
+	for (int s = 1; s <= p.nscale - 3; ++s) {                        // extrema.cc:42
+		const float* now = dog_plane(p, img, o, s);
+		const float center = now[idx];
+		if (center < p.pre_color_thres) continue;                    // :179
+		bool mx = true, mn = true;
+		const float cmp1 = center - p.judge_thres, cmp2 = center + p.judge_thres;
+#pragma unroll
+		for (int di = -1; di <= 1; ++di)
+#pragma unroll
+			for (int dj = -1; dj <= 1; ++dj) {
+				if (di == 0 && dj == 0) continue;
+				const float v = now[idx + di * w + dj];
+				if (v >= cmp1) mx = false;
+				if (v <= cmp2) mn = false;
+			}
+		if (!mx && !mn) continue;
+		for (int ds = -1; ds <= 1; ds += 2) {
+			const float* mat = dog_plane(p, img, o, s + ds);
+#pragma unroll
+			for (int di = -1; di <= 1; ++di)
+#pragma unroll
+				for (int dj = -1; dj <= 1; ++dj) {
+					const float v = mat[idx + di * w + dj];
+					if (v >= cmp1) mx = false;
+					if (v <= cmp2) mn = false;
+				}
+		}
+		if (!mx && !mn) continue;
+		const int slot = atomicAdd(&raw_count[img], 1);
+		if (slot < cap) {
+			int* q = raw + ((long long)img * cap + slot) * 4;
+			q[0] = c; q[1] = r; q[2] = o; q[3] = s;
+		}
+	}
+}
+
+// Eigen::FullPivLU 3x3 inverse as used by Matrix::inverse (lib/matrix.cc:76-87): complete
+// pivoting, rank threshold |pivot| > |maxpivot| * eps * 3, inverse = solve(Identity).
+__device__ bool inverse3_fullpiv(const double a[9], double inv[9]) {
+	double lu[9];
+#pragma unroll
+	for (int i = 0; i < 9; ++i) lu[i] = a[i];
+	int rowt[3], colt[3], nonzero = 3;
+	double maxpivot = 0;
+	for (int k = 0; k < 3; ++k) {
+		int br = k, bc = k; double best = -1;
+		for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j) {
+			double v = fabs(lu[i * 3 + j]);
+			if (v > best) { best = v; br = i; bc = j; }
+		}
+		if (best == 0.0) { nonzero = k; for (int i = k; i < 3; ++i) rowt[i] = colt[i] = i; break; }
+		if (best > maxpivot) maxpivot = best;
+		rowt[k] = br; colt[k] = bc;
+		if (br != k) for (int j = 0; j < 3; ++j) { double t = lu[k * 3 + j]; lu[k * 3 + j] = lu[br * 3 + j]; lu[br * 3 + j] = t; }
+		if (bc != k) for (int i = 0; i < 3; ++i) { double t = lu[i * 3 + k]; lu[i * 3 + k] = lu[i * 3 + bc]; lu[i * 3 + bc] = t; }
+		for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
+		for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j)
+			lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
+	}
+	const double thr = fabs(maxpivot) * (2.220446049250313e-16 * 3);
+	int rank = 0;
+	for (int i = 0; i < nonzero; ++i) rank += (fabs(lu[i * 3 + i]) > thr);
+	if (rank != 3) return false;
+	for (int col = 0; col < 3; ++col) {
+		double c[3];
+		for (int i = 0; i < 3; ++i) c[i] = (i == col) ? 1.0 : 0.0;
+		for (int i = 0; i < 3; ++i) { double t = c[i]; c[i] = c[rowt[i]]; c[rowt[i]] = t; }
+		for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
+		for (int i = 2; i >= 0; --i) {
+			for (int j = i + 1; j < 3; ++j) c[i] -= lu[i * 3 + j] * c[j];
+			c[i] /= lu[i * 3 + i];
+		}
+		for (int i = 2; i >= 0; --i) { double t = c[i]; c[i] = c[colt[i]]; c[colt[i]] = t; }
+		for (int i = 0; i < 3; ++i) inv[i * 3 + col] = c[i];
+	}
+	return true;
+}
+
+// Matrix::pseudo_inverse (lib/matrix.cc:89-106) of a 3x3 through a one-sided Jacobi SVD; only
+// reached for a rank-deficient Hessian.
+__device__ void pinv3_jacobi(const double a[9], double out[9]) {
+	double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	for (int i = 0; i < 9; ++i) A[i] = a[i];
+	for (int sweep = 0; sweep < 60; ++sweep) {
+		double off = 0;
+		for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+			double alpha = 0, beta = 0, gamma = 0;
+			for (int i = 0; i < 3; ++i) { alpha += A[i*3+p]*A[i*3+p]; beta += A[i*3+q]*A[i*3+q]; gamma += A[i*3+p]*A[i*3+q]; }
+			if (gamma == 0.0) continue;
+			double lim = sqrt(alpha * beta);
+			if (fabs(gamma) <= 1e-16 * lim) continue;
+			double rel = fabs(gamma) / (lim > 0 ? lim : 1);
+			if (rel > off) off = rel;
+			double zeta = (beta - alpha) / (2.0 * gamma);
+			double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+			double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+			for (int i = 0; i < 3; ++i) {
+				double x = A[i*3+p], y = A[i*3+q];
+				A[i*3+p] = cs * x - sn * y; A[i*3+q] = sn * x + cs * y;
+				x = V[i*3+p]; y = V[i*3+q];
+				V[i*3+p] = cs * x - sn * y; V[i*3+q] = sn * x + cs * y;
+			}
+		}
+		if (off < 1e-15) break;
+	}
+	for (int i = 0; i < 9; ++i) out[i] = 0;
+	for (int j = 0; j < 3; ++j) {
+		double s = 0;
+		for (int i = 0; i < 3; ++i) s += A[i*3+j] * A[i*3+j];
+		s = sqrt(s);
+		if (!(s > 1e-6)) continue;
+		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+			out[r*3+c] += V[r*3+j] * (1.0 / s) * (A[c*3+j] / s);
+	}
+}
+
+// ---- calc_kp_offset(_iter) + is_edge_response (feature/extrema.cc:63-168): thread per candidate
+__global__ void __launch_bounds__(128) k_refine(SiftPlan p, const int* raw, const int* raw_count, int cap,
+		KeyPoint* refined, int* refined_count) {
+	const int img = blockIdx.y;
+	const int i = blockIdx.x * 128 + threadIdx.x;
+	int n = raw_count[img]; n = n < cap ? n : cap;
+	if (i >= n) return;
+	const int* q = raw + ((long long)img * cap + i) * 4;
+	int nowx = q[0], nowy = q[1];
+	const int o = q[2];
+	int nows = q[3];
+	const OctDesc od = p.oct[o];
+	const int w = od.w, h = od.h, nscale = p.nscale;
+	const float* base = p.ws + (long long)img * p.ws_stride;
+	double offset[3] = {0, 0, 0}, delta[3] = {0, 0, 0};
+	int niter = 0;
+	for (; niter < p.calc_offset_depth; ++niter) {
+		if (!(nowx >= 1 && nowx <= w - 2) || !(nowy >= 1 && nowy <= h - 2) || !(nows >= 1 && nows <= nscale - 3))
+			return;
+		const float* d0 = base + plane_off_dog(od, nows - 1);
+		const float* d1 = base + plane_off_dog(od, nows);
+		const float* d2 = base + plane_off_dog(od, nows + 1);
+		const long long c = (long long)nowy * w + nowx;
+		const float val = d1[c];
+		const float xp = d1[c + 1], xm = d1[c - 1], yp = d1[c + w], ym = d1[c - w];
+		const float sp = d2[c], sm = d0[c];
+		delta[0] = (double)((xp - xm) / 2);
+		delta[1] = (double)((yp - ym) / 2);
+		delta[2] = (double)((sp - sm) / 2);
+		const double dxx = (double)(xp + xm - val - val);
+		const double dyy = (double)(yp + ym - val - val);
+		const double dss = (double)(sp + sm - val - val);
+		const double dxy = (double)((d1[c + w + 1] - d1[c - w + 1] - d1[c + w - 1] + d1[c - w - 1]) / 4);
+		const double dys = (double)((d2[c + w] - d2[c - w] - d0[c + w] + d0[c - w]) / 4);
+		const double dsx = (double)((d2[c + 1] - d2[c - 1] - d0[c + 1] + d0[c - 1]) / 4);
+		const double m[9] = {dxx, dxy, dsx, dxy, dyy, dys, dsx, dys, dss};
+		double inv[9];
+		if (!inverse3_fullpiv(m, inv)) pinv3_jacobi(m, inv);
+		for (int r = 0; r < 3; ++r) {
+			double acc = 0;
+			for (int k = 0; k < 3; ++k) acc += inv[r * 3 + k] * delta[k];
+			offset[r] = acc;
+		}
+		const double ax = fabs(offset[0]), ay = fabs(offset[1]), az = fabs(offset[2]);
+		double mx = ay > az ? ay : az; mx = ax > mx ? ax : mx;
+		if (mx < (double)p.offset_thres) break;
+		nowx = (int)((double)nowx + round(offset[0]));
+		nowy = (int)((double)nowy + round(offset[1]));
+		nows = (int)((double)nows + round(offset[2]));
+	}
+	if (niter == p.calc_offset_depth) return;
+	const float* dn = base + plane_off_dog(od, nows);
+	const long long c = (long long)nowy * w + nowx;
+	double dextr = offset[0] * delta[0] + offset[1] * delta[1] + offset[2] * delta[2];
+	dextr = (double)dn[c] + dextr / 2;
+	if (dextr < (double)p.contrast_thres) return;
+	// is_edge_response (:152-168) on the refined position
+	{
+		const float val = dn[c];
+		const float dxx = dn[c + 1] + dn[c - 1] - val - val;
+		const float dyy = dn[c + w] + dn[c - w] - val - val;
+		const float dxy = (dn[c + w + 1] + dn[c - w - 1] - dn[c + w - 1] - dn[c - w + 1]) / 4;
+		const float det = dxx * dyy - dxy * dxy;
+		if (det <= 0) return;
+		const float tr = dxx + dyy;
+		const float tr2 = tr * tr;
+		const float e1 = p.edge_ratio + 1;
+		if (!(tr2 / det < (e1 * e1) / p.edge_ratio)) return;
+	}
+	KeyPoint kp;
+	kp.x = nowx; kp.y = nowy; kp.oct = o; kp.scale = nows;
+	kp.sf = (float)((double)p.gauss_sigma * pow((double)p.scale_factor, ((double)nows + offset[2]) / nscale));
+	kp.rx = ((double)nowx + offset[0]) / w;
+	kp.ry = ((double)nowy + offset[1]) / h;
+	kp.dir = 0.f; kp.src = i; kp.pad = 0;
+	const int slot = atomicAdd(&refined_count[img], 1);
+	refined[(long long)img * cap + slot] = kp;
+}
+
+// canonical order of refined keypoints: (oct, scale, y, x, rx, ry), ties by candidate payload
+__device__ __forceinline__ bool kp_less(const KeyPoint& a, const KeyPoint& b) {
+	if (a.oct != b.oct) return a.oct < b.oct;
+	if (a.scale != b.scale) return a.scale < b.scale;
+	if (a.y != b.y) return a.y < b.y;
+	if (a.x != b.x) return a.x < b.x;
+	if (a.rx != b.rx) return a.rx < b.rx;
+	if (a.ry != b.ry) return a.ry < b.ry;
+	if (a.sf != b.sf) return a.sf < b.sf;
+	return false;
+}
+
+// rank sort, one workgroup per image (K is ~1e3; O(K^2) comparisons on 256 lanes)
+__global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const int* count, int cap, KeyPoint* out) {
+	const int img = blockIdx.x;
+	const int n = count[img];
+	const KeyPoint* a = in + (long long)img * cap;
+	KeyPoint* b = out + (long long)img * cap;
+	for (int i = threadIdx.x; i < n; i += 256) {
+		const KeyPoint me = a[i];
+		int rank = 0;
+		for (int j = 0; j < n; ++j) {
+			const KeyPoint& o = a[j];
+			// fully identical records tie-break on the slot index: any assignment is the same output
+			rank += (kp_less(o, me) || (!kp_less(me, o) && j < i)) ? 1 : 0;
+		}
+		KeyPoint w = me; w.src = rank;
+		b[rank] = w;
+	}
+}
+
+// ---- OrientationAssign::calc_dir (feature/orientation.cc:34-100): one wavefront per keypoint.
+// Samples are evaluated 64 at a time, but each histogram bin is accumulated by ONE lane walking
+// the samples in the reference's (xx outer, yy inner) order, so the fp32 sums round identically.
+constexpr int ORI_BINS = 36;
+constexpr int ORI_CHUNK = 1024;            // samples staged in LDS per pass (order-preserving chunks)
+
+__global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* refined, const int* refined_count,
+		int cap, float* dirs, int* ndirs) {
+	__shared__ float s_val[ORI_CHUNK];
+	__shared__ signed char s_bin[ORI_CHUNK];
+	__shared__ float s_hist[ORI_BINS];
+	const int img = blockIdx.y;
+	const int count = refined_count[img];
+	const int lane = threadIdx.x;
+	const float* base = p.ws + (long long)img * p.ws_stride;
+	const float halfipi = (float)(0.5f / 3.14159265358979323846);
+	for (int k = blockIdx.x; k < count; k += gridDim.x) {
+		const KeyPoint kp = refined[(long long)img * cap + k];
+		const OctDesc od = p.oct[kp.oct];
+		const float* mag_img = base + plane_off_mag(od, p.nscale, kp.scale);
+		const float* ort_img = base + plane_off_ort(od, p.nscale, kp.scale);
+		const float gauss_weight_sigma = kp.sf * 1.5f;                 // ORI_WINDOW_FACTOR
+		const int rad = (int)roundf(kp.sf * p.ori_radius);
+		const float exp_denom = 2 * (gauss_weight_sigma * gauss_weight_sigma);
+		const int side = 2 * rad, nsamp = side * side;
+		const float frad2 = (float)rad * (float)rad;
+		float h = 0.f;
+		for (int cb = 0; cb < nsamp; cb += ORI_CHUNK) {
+			const int cn = nsamp - cb < ORI_CHUNK ? nsamp - cb : ORI_CHUNK;
+			for (int i = lane; i < cn; i += 64) {
+				const int e = cb + i;
+				const int xx = e / side - rad, yy = e % side - rad;
+				const int newx = kp.x + xx, newy = kp.y + yy;
+				int bin = -1; float val = 0.f;
+				if (newx >= 1 && newx <= od.w - 2 && newy >= 1 && newy <= od.h - 2) {
+					const float fxx = (float)xx, fyy = (float)yy;
+					const float r2 = fxx * fxx + fyy * fyy;
+					if (!(r2 > frad2)) {
+						const long long gi = (long long)newy * od.w + newx;
+						const float orient = ort_img[gi];
+						bin = (int)roundf(36 * halfipi * orient);
+						if (bin == ORI_BINS) bin = 0;
+						const float weight = opdev::expf_glibc(-r2 / exp_denom);
+						val = weight * mag_img[gi];
+					}
+				}
+				s_bin[i] = (signed char)bin; s_val[i] = val;
+			}
+			__syncthreads();
+			if (lane < ORI_BINS)
+				for (int i = 0; i < cn; ++i)
+					if (s_bin[i] == lane) h += s_val[i];
+			__syncthreads();
+		}
+		if (lane < ORI_BINS) s_hist[lane] = h;
+		__syncthreads();
+		if (lane == 0) {   // in-place sequential smoothing (:70-75)
+			for (int K = p.ori_smooth; K--;)
+				for (int i = 0; i < ORI_BINS; ++i) {
+					const float prev = s_hist[i == 0 ? ORI_BINS - 1 : i - 1];
+					const float next = s_hist[i == ORI_BINS - 1 ? 0 : i + 1];
+					s_hist[i] = (float)((double)s_hist[i] * 0.5 + (double)(prev + next) * 0.25);
+				}
+		}
+		__syncthreads();
+		const float hv = lane < ORI_BINS ? s_hist[lane] : 0.f;
+		float maxbin = 0.f;
+		for (int i = 0; i < ORI_BINS; ++i) maxbin = maxbin < s_hist[i] ? s_hist[i] : maxbin;
+		const float thres = maxbin * 0.8f;                              // ORI_HIST_PEAK_RATIO
+		bool peak = false; float ort = 0.f;
+		if (lane < ORI_BINS) {
+			const float prev = s_hist[lane == 0 ? ORI_BINS - 1 : lane - 1];
+			const float next = s_hist[lane == ORI_BINS - 1 ? 0 : lane + 1];
+			const float mpn = prev < next ? next : prev;
+			if (hv > thres && hv > mpn) {
+				peak = true;
+				double newbin = (double)(float)lane - 0.5 + (double)((hv - prev) / (prev + next - 2 * hv));
+				if (newbin < 0) newbin += ORI_BINS;
+				else if (newbin >= ORI_BINS) newbin -= ORI_BINS;
+				ort = (float)(newbin / ORI_BINS * 2 * 3.14159265358979323846);
+			}
+		}
+		const unsigned long long mask = __ballot(peak);
+		const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
+		float* out = dirs + ((long long)img * cap + k) * ORI_BINS;
+		if (peak) out[pos] = ort;
+		if (lane == 0) ndirs[(long long)img * cap + k] = __popcll(mask);
+		__syncthreads();
+	}
+}
+
+// per-image total of orientation peaks (one workgroup per image)
+__global__ void __launch_bounds__(256) k_count_oriented(const int* refined_count, int cap, const int* ndirs, int* per_image) {
+	__shared__ int s_sum[256];
+	const int img = blockIdx.x;
+	const int n = refined_count[img];
+	int acc = 0;
+	for (int i = threadIdx.x; i < n; i += 256) acc += ndirs[(long long)img * cap + i];
+	s_sum[threadIdx.x] = acc;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (threadIdx.x < st) s_sum[threadIdx.x] += s_sum[threadIdx.x + st];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) per_image[img] = s_sum[0];
+}
+
+// expansion refined -> oriented in (refined order, peak order): OrientationAssign::work (:22-32)
+__global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
+		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented) {
+	__shared__ int s_scan[256];
+	__shared__ int s_base;
+	const int img = blockIdx.x;
+	const int n = refined_count[img];
+	if (threadIdx.x == 0) s_base = 0;
+	__syncthreads();
+	for (int start = 0; start < n; start += 256) {
+		const int i = start + threadIdx.x;
+		const int cnt = i < n ? ndirs[(long long)img * cap + i] : 0;
+		s_scan[threadIdx.x] = cnt;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) {          // inclusive Hillis-Steele scan
+			int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+			__syncthreads();
+			s_scan[threadIdx.x] += v;
+			__syncthreads();
+		}
+		const int excl = s_scan[threadIdx.x] - cnt + s_base;
+		if (i < n) {
+			KeyPoint kp = refined[(long long)img * cap + i];
+			const float* d = dirs + ((long long)img * cap + i) * ORI_BINS;
+			for (int j = 0; j < cnt; ++j) {
+				kp.dir = d[j]; kp.src = i;
+				oriented[img_offset[img] + excl + j] = kp;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 255) s_base += s_scan[255];
+		__syncthreads();
+	}
+}
+
+}	// namespace
+
+hipError_t launch_extrema_scan(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
+	dim3 grid((unsigned)((p.oct[0].plane + 255) / 256), p.noct, p.n);
+	hipLaunchKernelGGL(k_extrema_scan, grid, dim3(256), 0, st, p, raw, raw_count, cap);
+	return hipGetLastError();
+}
+
+hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap,
+		KeyPoint* refined, int* refined_count, hipStream_t st) {
+	// grid covers the capacity; threads beyond the live count exit immediately
+	dim3 grid((cap + 127) / 128, p.n);
+	hipLaunchKernelGGL(k_refine, grid, dim3(128), 0, st, p, raw, raw_count, cap, refined, refined_count);
+	return hipGetLastError();
+}
+
+hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
+		KeyPoint* out, hipStream_t st) {
+	hipLaunchKernelGGL(k_sort_refined, dim3(p.n), dim3(256), 0, st, in, count, cap, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+		float* dirs, int* ndirs, hipStream_t st) {
+	// grid-stride over the (device-side) keypoint count: no host round trip for the count
+	dim3 grid(cap < 1024 ? cap : 1024, p.n);
+	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs, ndirs);
+	return hipGetLastError();
+}
+
+hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
+		int* per_image, hipStream_t st) {
+	hipLaunchKernelGGL(k_count_oriented, dim3(p.n), dim3(256), 0, st, refined_count, cap, ndirs, per_image);
+	return hipGetLastError();
+}
+
+hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, hipStream_t st) {
+	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, img_offset, oriented);
+	return hipGetLastError();
+}

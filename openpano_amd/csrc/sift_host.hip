@@ -1,0 +1,437 @@
+// sift_host.hip -- host orchestration of the batched SIFT op (op_sift_batch / op_sift_staged).
+//
+// Mirrors SIFTDetector::do_detect_feature (feature/feature.cc:31-47) for n images at once:
+// one launch per stage for the whole batch (grid z/y = image), everything resident in HBM,
+// two small D2H reads of per-image counts (the caller needs K_i anyway).
+#include "internal.hpp"
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+size_t pyramid_lds_bytes(int halo);
+
+namespace {
+
+struct DevBuf {
+	void* p = nullptr; size_t cap = 0;
+	hipError_t ensure(size_t bytes) {
+		if (bytes <= cap) return hipSuccess;
+		if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) return e;
+		cap = want;
+		return hipSuccess;
+	}
+	void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+}	// namespace
+
+struct Workspace {
+	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, offsets, oriented;
+	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch for counts/offsets
+	void release() {
+		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
+		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); offsets.release(); oriented.release();
+		if (pinned) hipHostFree(pinned); pinned = nullptr; pinned_cap = 0;
+	}
+};
+
+static std::map<op_ctx*, Workspace*> g_ws;   // contexts are few and long-lived
+
+static Workspace* ctx_workspace(op_ctx* c) {
+	auto it = g_ws.find(c);
+	if (it != g_ws.end()) return it->second;
+	Workspace* w = new Workspace;
+	g_ws[c] = w;
+	return w;
+}
+void op_ctx_release_workspace(op_ctx* c) {
+	auto it = g_ws.find(c);
+	if (it == g_ws.end()) return;
+	it->second->release(); delete it->second; g_ws.erase(it);
+}
+
+struct op_features {
+	int n = 0;
+	std::vector<int> counts;
+	std::vector<int64_t> offsets;      // n + 1
+	float* desc = nullptr;             // device, total x 128
+	double* coor = nullptr;            // device, total x 2
+	int device = 0;
+};
+
+struct op_sift_dump {
+	Workspace w;                       // private workspace kept alive for plane reads
+	SiftPlan plan;
+	int cap = 0;
+	std::vector<int> raw;              // sorted (o, s, y, x) quads: x, y, o, s
+	std::vector<KeyPoint> refined, oriented;
+	std::vector<float> desc; std::vector<double> coor01;
+};
+
+namespace {
+
+constexpr int kCap = 16384;            // per-image capacity of raw / refined keypoint lists
+
+// feature/gaussian.cc:17-40 (GaussCache) + gaussian.hh:96-103 (sigma bank), host side
+int build_gauss_bank(const op_config& cfg, SiftPlan& p) {
+	float sigma = cfg.GAUSS_SIGMA;
+	p.halo = 0;
+	memset(p.kern, 0, sizeof(p.kern));
+	memset(p.kcenter, 0, sizeof(p.kcenter));
+	for (int s = 1; s < cfg.NUM_SCALE; ++s) {
+		int kw = (int)(std::ceil(0.3 * (sigma / 2 - 1) + 0.8) * cfg.GAUSS_WINDOW_FACTOR);
+		if (kw % 2 == 0) kw++;
+		const int center = kw / 2;
+		if (center > OP_MAX_KCENTER || kw < 1) return -1;
+		float* kernel = &p.kern[s][OP_MAX_KCENTER];
+		kernel[0] = 1;
+		float exp_coeff = (float)(-1.0 / (sigma * sigma * 2)), wsum = 1;
+		for (int i = 1; i <= center; i++)
+			wsum += (kernel[i] = std::exp((float)(i * i) * exp_coeff)) * 2;   // std::exp(float) = expf
+		float fac = (float)(1.0 / wsum);
+		kernel[0] = fac;
+		for (int i = 1; i <= center; i++)
+			kernel[-i] = (kernel[i] *= fac);
+		p.kcenter[s] = center;
+		p.halo = std::max(p.halo, center);
+		sigma *= cfg.SCALE_FACTOR;
+	}
+	return 0;
+}
+
+int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
+	memset(&p, 0, sizeof(p));
+	if (cfg.NUM_OCTAVE < 1 || cfg.NUM_OCTAVE > OP_MAX_OCT || cfg.NUM_SCALE < 4 || cfg.NUM_SCALE > OP_MAX_SCALE)
+		OP_FAIL(OP_ERR_UNSUPPORTED, "NUM_OCTAVE must be in [1,8] and NUM_SCALE in [4,12]");
+	if (sh < 2 || sw < 2) OP_FAIL(OP_ERR_INVALID, "image must be at least 2x2 (lib/imgproc.cc:321)");
+	p.n = n; p.sh = sh; p.sw = sw;
+	// feature/feature.cc:33-34
+	float ratio = cfg.SIFT_WORKING_SIZE * 2.0f / (sw + sh);
+	p.wh = (int)(sh * ratio); p.ww = (int)(sw * ratio);
+	if (p.wh < 2 || p.ww < 2) OP_FAIL(OP_ERR_INVALID, "working image degenerate");
+	p.noct = cfg.NUM_OCTAVE; p.nscale = cfg.NUM_SCALE;
+	long long off = 0; int tile_begin = 0;
+	for (int i = 0; i < p.noct; ++i) {
+		OctDesc& o = p.oct[i];
+		if (i == 0) { o.h = p.wh; o.w = p.ww; }
+		else {      // feature/dog.cc:105-107
+			float factor = (float)std::pow((double)cfg.SCALE_FACTOR, (double)-i);
+			o.w = (int)std::ceil(p.ww * factor); o.h = (int)std::ceil(p.wh * factor);
+			if (!(o.w > 5 && o.h > 5)) OP_FAIL(OP_ERR_INVALID, "octave smaller than 6 px (feature/dog.cc:108 assertion)");
+		}
+		o.plane = (long long)o.h * o.w;
+		o.off = off; off += o.plane * planes_per_octave(p.nscale);
+		o.tiles_x = (o.w + OP_PYR_TW - 1) / OP_PYR_TW; o.tiles_y = (o.h + OP_PYR_TH - 1) / OP_PYR_TH;
+		o.tile_begin = tile_begin; tile_begin += o.tiles_x * o.tiles_y;
+	}
+	p.total_tiles = tile_begin;
+	p.ws_stride = (off + 63) & ~63LL;
+	if (build_gauss_bank(cfg, p) != 0) OP_FAIL(OP_ERR_UNSUPPORTED, "Gaussian kernel wider than 31 taps");
+	if (pyramid_lds_bytes(p.halo) > 160 * 1024 - 256) OP_FAIL(OP_ERR_UNSUPPORTED, "Gaussian halo does not fit LDS");
+	p.pre_color_thres = cfg.PRE_COLOR_THRES; p.judge_thres = cfg.JUDGE_EXTREMA_DIFF_THRES;
+	p.contrast_thres = cfg.CONTRAST_THRES; p.edge_ratio = cfg.EDGE_RATIO; p.offset_thres = cfg.OFFSET_THRES;
+	p.calc_offset_depth = cfg.CALC_OFFSET_DEPTH;
+	p.gauss_sigma = cfg.GAUSS_SIGMA; p.scale_factor = cfg.SCALE_FACTOR; p.ori_radius = cfg.ORI_RADIUS;
+	p.ori_smooth = cfg.ORI_HIST_SMOOTH_COUNT; p.desc_scale_factor = cfg.DESC_HIST_SCALE_FACTOR;
+	p.desc_int_factor = cfg.DESC_INT_FACTOR;
+	return OP_OK;
+}
+
+struct GroupResult {
+	std::vector<int> counts;          // per image of the group
+	float* desc = nullptr; double* coor = nullptr;   // device (hipMalloc), group-local flat
+	long long total = 0;
+};
+
+// Run the whole pipeline for images of one size. `keep` (staged dump) additionally copies the
+// intermediate lists to the host.
+int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_image*>& imgs, Workspace& W,
+		SiftPlan& plan, GroupResult& res, op_sift_dump* keep) {
+	const int n = (int)imgs.size();
+	const int sh = imgs[0]->h, sw = imgs[0]->w;
+	int rc = build_plan(cfg, n, sh, sw, plan);
+	if (rc != OP_OK) return rc;
+	hipStream_t st = ctx->stream;
+	const int cap = kCap;
+
+	// --- buffers
+	HIPCHK(W.ws.ensure(sizeof(float) * (size_t)plan.ws_stride * n));
+	HIPCHK(W.work.ensure(sizeof(float) * (size_t)plan.wh * plan.ww * 3 * n));
+	HIPCHK(W.srcs.ensure(sizeof(float*) * n));
+	HIPCHK(W.raw.ensure(sizeof(int) * 4 * (size_t)cap * n));
+	HIPCHK(W.counts.ensure(sizeof(int) * 4 * n));            // raw | refined | oriented | spare
+	HIPCHK(W.refinedA.ensure(sizeof(KeyPoint) * (size_t)cap * n));
+	HIPCHK(W.refinedB.ensure(sizeof(KeyPoint) * (size_t)cap * n));
+	HIPCHK(W.dirs.ensure(sizeof(float) * 36 * (size_t)cap * n));
+	HIPCHK(W.ndirs.ensure(sizeof(int) * (size_t)cap * n));
+	HIPCHK(W.offsets.ensure(sizeof(long long) * (n + 1)));
+	const size_t pin_need = sizeof(long long) * (size_t)(8 * n + 16);
+	if (W.pinned_cap < pin_need) {
+		if (W.pinned) hipHostFree(W.pinned);
+		HIPCHK(hipHostMalloc(&W.pinned, pin_need));
+		W.pinned_cap = pin_need;
+	}
+	plan.ws = (float*)W.ws.p; plan.work = (float*)W.work.p;
+
+	// --- sources: device pointers as they are, host images staged through one H2D copy each
+	size_t host_bytes = 0;
+	for (auto* im : imgs) if (!im->on_device) host_bytes += sizeof(float) * (size_t)sh * sw * 3;
+	if (host_bytes) HIPCHK(W.staging.ensure(host_bytes));
+	{
+		const float** hs = (const float**)W.pinned;
+		size_t so = 0;
+		for (int i = 0; i < n; ++i) {
+			if (imgs[i]->on_device) hs[i] = imgs[i]->data;
+			else {
+				float* d = (float*)((char*)W.staging.p + so);
+				HIPCHK(hipMemcpyAsync(d, imgs[i]->data, sizeof(float) * (size_t)sh * sw * 3, hipMemcpyHostToDevice, st));
+				hs[i] = d; so += sizeof(float) * (size_t)sh * sw * 3;
+			}
+		}
+		HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(float*) * n, hipMemcpyHostToDevice, st));
+	}
+	plan.srcs = (const float* const*)W.srcs.p;
+
+	int* d_raw_count = (int*)W.counts.p;
+	int* d_refined_count = d_raw_count + n;
+	int* d_oriented_count = d_raw_count + 2 * n;
+	HIPCHK(hipMemsetAsync(W.counts.p, 0, sizeof(int) * 4 * n, st));
+
+	HIPCHK(launch_resize_to_work(plan, st));
+	HIPCHK(launch_octave_grey(plan, st));
+	HIPCHK(launch_pyramid(plan, st));
+	HIPCHK(launch_extrema_scan(plan, (int*)W.raw.p, d_raw_count, cap, st));
+	HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
+	HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st));
+	HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, st));
+	HIPCHK(launch_count_oriented(plan, d_refined_count, cap, (const int*)W.ndirs.p, d_oriented_count, st));
+
+	// pinned scratch regions: [0,8n) source table | [16n,28n) counts | [32n, 40n+8) offsets
+	int* h_counts = (int*)((char*)W.pinned + 16 * (size_t)n);
+	HIPCHK(hipMemcpyAsync(h_counts, W.counts.p, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	std::vector<int> raw_count(h_counts, h_counts + n), refined_count(h_counts + n, h_counts + 2 * n);
+	res.counts.assign(h_counts + 2 * n, h_counts + 3 * n);
+	for (int i = 0; i < n; ++i)
+		if (raw_count[i] > cap)
+			OP_FAIL(OP_ERR_CAPACITY, "raw extrema list overflow: " + std::to_string(raw_count[i]) + " > " + std::to_string(cap));
+	long long* h_off = (long long*)((char*)W.pinned + 32 * (size_t)n);
+	long long total = 0;
+	std::vector<long long> offs(n + 1);
+	for (int i = 0; i < n; ++i) { offs[i] = total; total += res.counts[i]; }
+	offs[n] = total;
+	memcpy(h_off, offs.data(), sizeof(long long) * (n + 1));
+	HIPCHK(hipMemcpyAsync(W.offsets.p, h_off, sizeof(long long) * (n + 1), hipMemcpyHostToDevice, st));
+	res.total = total;
+	HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(hipMalloc(&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(hipMalloc(&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
+				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st));
+	HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, st));
+	HIPCHK(hipStreamSynchronize(st));     // h_off (pinned) consumed; results ready
+
+	if (keep) {
+		keep->cap = cap;
+		keep->raw.resize((size_t)raw_count[0] * 4);
+		if (raw_count[0]) HIPCHK(hipMemcpy(keep->raw.data(), W.raw.p, sizeof(int) * 4 * raw_count[0], hipMemcpyDeviceToHost));
+		keep->refined.resize(refined_count[0]);
+		if (refined_count[0]) HIPCHK(hipMemcpy(keep->refined.data(), W.refinedB.p, sizeof(KeyPoint) * refined_count[0], hipMemcpyDeviceToHost));
+		keep->oriented.resize(total);
+		if (total) HIPCHK(hipMemcpy(keep->oriented.data(), W.oriented.p, sizeof(KeyPoint) * total, hipMemcpyDeviceToHost));
+		keep->desc.resize((size_t)total * 128);
+		if (total) HIPCHK(hipMemcpy(keep->desc.data(), res.desc, sizeof(float) * 128 * total, hipMemcpyDeviceToHost));
+		// sort the raw list into scan order (o, s, y, x)
+		std::vector<std::array<int, 4>> q(raw_count[0]);
+		for (int i = 0; i < raw_count[0]; ++i) q[i] = {keep->raw[4 * i + 2], keep->raw[4 * i + 3], keep->raw[4 * i + 1], keep->raw[4 * i]};
+		std::sort(q.begin(), q.end());
+		for (int i = 0; i < raw_count[0]; ++i) { keep->raw[4 * i] = q[i][3]; keep->raw[4 * i + 1] = q[i][2]; keep->raw[4 * i + 2] = q[i][0]; keep->raw[4 * i + 3] = q[i][1]; }
+	}
+	return OP_OK;
+}
+
+}	// namespace
+
+extern "C" {
+
+int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n, op_features** out) {
+	if (!ctx || !cfg || !imgs || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_sift_batch: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	for (int i = 0; i < n; ++i)
+		if (!imgs[i].data || imgs[i].h < 2 || imgs[i].w < 2) OP_FAIL(OP_ERR_INVALID, "op_sift_batch: bad image " + std::to_string(i));
+	// group by size, keep first-appearance order
+	std::vector<std::pair<std::pair<int, int>, std::vector<int>>> groups;
+	for (int i = 0; i < n; ++i) {
+		std::pair<int, int> key(imgs[i].h, imgs[i].w);
+		bool found = false;
+		for (auto& g : groups) if (g.first == key) { g.second.push_back(i); found = true; break; }
+		if (!found) groups.push_back({key, {i}});
+	}
+	Workspace* W = ctx_workspace(ctx);
+	op_features* f = new op_features;
+	f->n = n; f->counts.assign(n, 0); f->offsets.assign(n + 1, 0); f->device = ctx->device;
+	std::vector<GroupResult> results(groups.size());
+	for (size_t g = 0; g < groups.size(); ++g) {
+		std::vector<const op_image*> gi;
+		for (int idx : groups[g].second) gi.push_back(&imgs[idx]);
+		SiftPlan plan;
+		int rc = run_group(ctx, *cfg, gi, *W, plan, results[g], nullptr);
+		if (rc != OP_OK) {
+			for (auto& r : results) { if (r.desc) hipFree(r.desc); if (r.coor) hipFree(r.coor); }
+			delete f; return rc;
+		}
+		for (size_t k = 0; k < gi.size(); ++k) f->counts[groups[g].second[k]] = results[g].counts[k];
+	}
+	int64_t total = 0;
+	for (int i = 0; i < n; ++i) { f->offsets[i] = total; total += f->counts[i]; }
+	f->offsets[n] = total;
+	if (groups.size() == 1) {
+		f->desc = results[0].desc; f->coor = results[0].coor;
+	} else {
+		HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
+		HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+		for (size_t g = 0; g < groups.size(); ++g) {
+			long long go = 0;
+			for (size_t k = 0; k < groups[g].second.size(); ++k) {
+				int idx = groups[g].second[k]; int c = results[g].counts[k];
+				if (c) {
+					HIPCHK(hipMemcpyAsync(f->desc + f->offsets[idx] * 128, results[g].desc + go * 128, sizeof(float) * 128 * c, hipMemcpyDeviceToDevice, ctx->stream));
+					HIPCHK(hipMemcpyAsync(f->coor + f->offsets[idx] * 2, results[g].coor + go * 2, sizeof(double) * 2 * c, hipMemcpyDeviceToDevice, ctx->stream));
+				}
+				go += c;
+			}
+		}
+		HIPCHK(hipStreamSynchronize(ctx->stream));
+		for (auto& r : results) { hipFree(r.desc); hipFree(r.coor); }
+	}
+	*out = f;
+	return OP_OK;
+}
+
+int op_features_num_images(const op_features* f) { return f ? f->n : 0; }
+int op_features_count(const op_features* f, int i) { return (f && i >= 0 && i < f->n) ? f->counts[i] : 0; }
+int64_t op_features_offset(const op_features* f, int i) { return (f && i >= 0 && i <= f->n) ? f->offsets[i] : 0; }
+int64_t op_features_total(const op_features* f) { return f ? f->offsets[f->n] : 0; }
+const float* op_features_desc_device(const op_features* f) { return f ? f->desc : nullptr; }
+const double* op_features_coor_device(const op_features* f) { return f ? f->coor : nullptr; }
+
+int op_features_copy(op_ctx* ctx, const op_features* f, int i, float* desc, double* coor) {
+	if (!ctx || !f || i < 0 || i >= f->n) OP_FAIL(OP_ERR_INVALID, "op_features_copy: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	const int c = f->counts[i];
+	if (c == 0) return OP_OK;
+	if (desc) HIPCHK(hipMemcpyAsync(desc, f->desc + f->offsets[i] * 128, sizeof(float) * 128 * c, hipMemcpyDeviceToHost, ctx->stream));
+	if (coor) HIPCHK(hipMemcpyAsync(coor, f->coor + f->offsets[i] * 2, sizeof(double) * 2 * c, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return OP_OK;
+}
+
+int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* const* coor, const int* counts, int n, op_features** out) {
+	if (!ctx || !desc || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_from_host: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	op_features* f = new op_features;
+	f->n = n; f->counts.assign(counts, counts + n); f->offsets.assign(n + 1, 0); f->device = ctx->device;
+	int64_t total = 0;
+	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
+	f->offsets[n] = total;
+	HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
+	HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+	HIPCHK(hipMemsetAsync(f->coor, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1), ctx->stream));
+	for (int i = 0; i < n; ++i) {
+		if (!counts[i]) continue;
+		HIPCHK(hipMemcpyAsync(f->desc + f->offsets[i] * 128, desc[i], sizeof(float) * 128 * counts[i], hipMemcpyHostToDevice, ctx->stream));
+		if (coor && coor[i]) HIPCHK(hipMemcpyAsync(f->coor + f->offsets[i] * 2, coor[i], sizeof(double) * 2 * counts[i], hipMemcpyHostToDevice, ctx->stream));
+	}
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	*out = f;
+	return OP_OK;
+}
+
+void op_features_free(op_features* f) {
+	if (!f) return;
+	hipSetDevice(f->device);
+	if (f->desc) hipFree(f->desc);
+	if (f->coor) hipFree(f->coor);
+	delete f;
+}
+
+// ---- staged dump ----
+int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_sift_dump** out) {
+	if (!ctx || !cfg || !img || !img->data || !out) OP_FAIL(OP_ERR_INVALID, "op_sift_staged: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	op_sift_dump* d = new op_sift_dump;
+	GroupResult res;
+	std::vector<const op_image*> gi{img};
+	int rc = run_group(ctx, *cfg, gi, d->w, d->plan, res, d);
+	if (rc == OP_OK && res.total) {
+		d->coor01.resize((size_t)res.total * 2);
+		for (long long i = 0; i < res.total; ++i) { d->coor01[2 * i] = d->oriented[i].rx; d->coor01[2 * i + 1] = d->oriented[i].ry; }
+	}
+	if (res.desc) hipFree(res.desc);
+	if (res.coor) hipFree(res.coor);
+	if (rc != OP_OK) { d->w.release(); delete d; return rc; }
+	*out = d;
+	return OP_OK;
+}
+
+void op_sift_dump_free(op_sift_dump* d) { if (!d) return; d->w.release(); delete d; }
+
+int op_sift_dump_working_dims(const op_sift_dump* d, int* h, int* w) { *h = d->plan.wh; *w = d->plan.ww; return OP_OK; }
+int op_sift_dump_octave_dims(const op_sift_dump* d, int oct, int* h, int* w) {
+	if (oct < 0 || oct >= d->plan.noct) OP_FAIL(OP_ERR_INVALID, "bad octave");
+	*h = d->plan.oct[oct].h; *w = d->plan.oct[oct].w; return OP_OK;
+}
+
+int op_sift_dump_plane(op_ctx* ctx, const op_sift_dump* d, int kind, int oct, int s, float* out) {
+	if (!ctx || !d || !out) OP_FAIL(OP_ERR_INVALID, "op_sift_dump_plane: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	const SiftPlan& p = d->plan;
+	if (kind == 4) {
+		HIPCHK(hipMemcpy(out, p.work, sizeof(float) * (size_t)p.wh * p.ww * 3, hipMemcpyDeviceToHost));
+		return OP_OK;
+	}
+	if (oct < 0 || oct >= p.noct) OP_FAIL(OP_ERR_INVALID, "bad octave");
+	const OctDesc& o = p.oct[oct];
+	long long off;
+	if (kind == 5) off = plane_off_grey(o);
+	else if (kind == 1 && s >= 0 && s <= p.nscale - 2) off = plane_off_dog(o, s);
+	else if (kind == 2 && s >= 1 && s <= p.nscale - 3) off = plane_off_mag(o, p.nscale, s);
+	else if (kind == 3 && s >= 1 && s <= p.nscale - 3) off = plane_off_ort(o, p.nscale, s);
+	else OP_FAIL(OP_ERR_INVALID, "bad plane kind/scale");
+	HIPCHK(hipMemcpy(out, p.ws + off, sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost));
+	return OP_OK;
+}
+
+int op_sift_dump_raw_count(const op_sift_dump* d, int oct, int s) {
+	int c = 0;
+	for (size_t i = 0; i < d->raw.size() / 4; ++i) c += (d->raw[4 * i + 2] == oct && d->raw[4 * i + 3] == s);
+	return c;
+}
+int op_sift_dump_raw(const op_sift_dump* d, int oct, int s, int* xy) {
+	int c = 0;
+	for (size_t i = 0; i < d->raw.size() / 4; ++i)
+		if (d->raw[4 * i + 2] == oct && d->raw[4 * i + 3] == s) { xy[2 * c] = d->raw[4 * i]; xy[2 * c + 1] = d->raw[4 * i + 1]; ++c; }
+	return c;
+}
+int op_sift_dump_kp_count(const op_sift_dump* d, int which) { return (int)(which ? d->oriented.size() : d->refined.size()); }
+int op_sift_dump_kp(const op_sift_dump* d, int which, int* ints, double* real, float* fl) {
+	const std::vector<KeyPoint>& v = which ? d->oriented : d->refined;
+	for (size_t i = 0; i < v.size(); ++i) {
+		ints[4 * i] = v[i].x; ints[4 * i + 1] = v[i].y; ints[4 * i + 2] = v[i].oct; ints[4 * i + 3] = v[i].scale;
+		real[2 * i] = v[i].rx; real[2 * i + 1] = v[i].ry;
+		fl[2 * i] = which ? v[i].dir : 0.f; fl[2 * i + 1] = v[i].sf;
+	}
+	return OP_OK;
+}
+int op_sift_dump_desc(const op_sift_dump* d, float* desc, double* coor) {
+	if (desc && !d->desc.empty()) memcpy(desc, d->desc.data(), sizeof(float) * d->desc.size());
+	if (coor && !d->coor01.empty()) memcpy(coor, d->coor01.data(), sizeof(double) * d->coor01.size());
+	return OP_OK;
+}
+
+}	// extern "C"

@@ -1,0 +1,307 @@
+"""ctypes binding of ``libopenpano_hip.so`` (the C-ABI in ``include/openpano_hip.h``).
+
+There is deliberately no fallback: if the HIP library is missing or no gfx950 device is
+present, loading / creating a context raises.  Device buffers can be handed over as raw
+pointers (e.g. ``torch.Tensor.data_ptr()``), PyTorch is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopenpano_hip.so")
+
+
+class OpenPanoHipError(RuntimeError):
+    pass
+
+
+class OpConfig(C.Structure):
+    """``op_config`` (include/openpano_hip.h), POD snapshot of ``namespace config``."""
+    _fields_ = [
+        ("SIFT_WORKING_SIZE", C.c_int), ("NUM_OCTAVE", C.c_int), ("NUM_SCALE", C.c_int),
+        ("SCALE_FACTOR", C.c_float), ("GAUSS_SIGMA", C.c_float), ("GAUSS_WINDOW_FACTOR", C.c_int),
+        ("JUDGE_EXTREMA_DIFF_THRES", C.c_float), ("CONTRAST_THRES", C.c_float),
+        ("PRE_COLOR_THRES", C.c_float), ("EDGE_RATIO", C.c_float),
+        ("CALC_OFFSET_DEPTH", C.c_int), ("OFFSET_THRES", C.c_float),
+        ("ORI_RADIUS", C.c_float), ("ORI_HIST_SMOOTH_COUNT", C.c_int),
+        ("DESC_HIST_SCALE_FACTOR", C.c_int), ("DESC_INT_FACTOR", C.c_int),
+        ("MATCH_REJECT_NEXT_RATIO", C.c_float), ("RANSAC_ITERATIONS", C.c_int),
+        ("RANSAC_INLIER_THRES", C.c_double),
+        ("INLIER_IN_MATCH_RATIO", C.c_float), ("INLIER_IN_POINTS_RATIO", C.c_float),
+        ("CYLINDER", C.c_int), ("TRANS", C.c_int), ("ESTIMATE_CAMERA", C.c_int),
+        ("ORDERED_INPUT", C.c_int), ("LAZY_READ", C.c_int), ("MULTIBAND", C.c_int),
+        ("MAX_OUTPUT_SIZE", C.c_int), ("FOCAL_LENGTH", C.c_float),
+    ]
+
+    @classmethod
+    def from_config(cls, cfg):
+        c = cls()
+        for name, _ in cls._fields_:
+            setattr(c, name, getattr(cfg, name))
+        return c
+
+
+class OpImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int)]
+
+
+_lib = None
+
+
+def _bind_torch_hip_runtime():
+    """Share ONE HIP runtime with PyTorch.
+
+    The PyTorch ROCm wheel bundles its own ``libamdhip64.so`` (same SONAME as /opt/rocm's).  Two
+    runtime instances in one process cannot see each other's allocations or streams (and the
+    second one finds no GPU), so when torch is installed its copy is loaded first -- by path,
+    without importing torch -- and ``libopenpano_hip.so`` then resolves ``libamdhip64.so.7`` to
+    it.  Without torch (plain C++ hosts) the system ROCm runtime is used.
+    """
+    import importlib.util
+    import sys
+    if os.environ.get("OPENPANO_SYSTEM_HIP"):
+        return
+    try:
+        spec = sys.modules["torch"].__spec__ if "torch" in sys.modules else importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=os.RTLD_NOW | os.RTLD_GLOBAL)
+
+
+def lib():
+    """Load the HIP library (once). Raises if it has not been built -- no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OpenPanoHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C openpano_amd/csrc`; openpano_amd has no CPU fallback")
+    _bind_torch_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    L.op_last_error.restype = C.c_char_p
+    L.op_abi_version.restype = C.c_int
+    L.op_config_default.argtypes = [C.POINTER(OpConfig)]
+    L.op_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.op_ctx_destroy.argtypes = [C.c_void_p]
+    L.op_ctx_sync.argtypes = [C.c_void_p]
+    L.op_sift_batch.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_features_num_images.argtypes = [C.c_void_p]
+    L.op_features_count.argtypes = [C.c_void_p, C.c_int]
+    L.op_features_offset.restype = C.c_int64
+    L.op_features_offset.argtypes = [C.c_void_p, C.c_int]
+    L.op_features_total.restype = C.c_int64
+    L.op_features_total.argtypes = [C.c_void_p]
+    L.op_features_desc_device.restype = C.c_void_p
+    L.op_features_desc_device.argtypes = [C.c_void_p]
+    L.op_features_coor_device.restype = C.c_void_p
+    L.op_features_coor_device.argtypes = [C.c_void_p]
+    L.op_features_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.op_features_from_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_features_free.argtypes = [C.c_void_p]
+    L.op_sift_staged.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.POINTER(C.c_void_p)]
+    L.op_sift_dump_free.argtypes = [C.c_void_p]
+    L.op_sift_dump_working_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_sift_dump_octave_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_sift_dump_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.op_sift_dump_raw_count.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.op_sift_dump_raw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.op_sift_dump_kp_count.argtypes = [C.c_void_p, C.c_int]
+    L.op_sift_dump_kp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.op_sift_dump_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.op_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "op_match_pairs"):
+        L.op_match_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.op_matches_count.argtypes = [C.c_void_p, C.c_int]
+        L.op_matches_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.op_matches_total.restype = C.c_int64
+        L.op_matches_total.argtypes = [C.c_void_p]
+        L.op_matches_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise OpenPanoHipError(f"libopenpano_hip error {rc}: {lib().op_last_error().decode(errors='replace')}")
+
+
+class Context:
+    """``op_ctx``: one per (process, device); ``stream`` is an optional raw ``hipStream_t``."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.handle = C.c_void_p()
+        check(lib().op_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+        self.device = device
+
+    def sync(self):
+        check(lib().op_ctx_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().op_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _mk_images(images):
+    """images: list of numpy HWC float32 arrays, or (device_ptr, h, w) tuples."""
+    arr = (OpImage * len(images))()
+    keep = []
+    for i, im in enumerate(images):
+        if isinstance(im, tuple):
+            ptr, h, w = im
+            arr[i] = OpImage(C.c_void_p(int(ptr)), int(h), int(w), 1)
+        else:
+            a = np.ascontiguousarray(im, np.float32)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("image must be H x W x 3 float32")
+            keep.append(a)
+            arr[i] = OpImage(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0)
+    return arr, keep
+
+
+class Features:
+    """``op_features``: device-resident descriptors/coordinates of a batch of images."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    @property
+    def num_images(self):
+        return lib().op_features_num_images(self.handle)
+
+    def count(self, i):
+        return lib().op_features_count(self.handle, i)
+
+    @property
+    def total(self):
+        return lib().op_features_total(self.handle)
+
+    def offset(self, i):
+        return lib().op_features_offset(self.handle, i)
+
+    @property
+    def desc_ptr(self):
+        return lib().op_features_desc_device(self.handle)
+
+    @property
+    def coor_ptr(self):
+        return lib().op_features_coor_device(self.handle)
+
+    def get(self, i):
+        k = self.count(i)
+        desc = np.empty((k, 128), np.float32); coor = np.empty((k, 2), np.float64)
+        check(lib().op_features_copy(self.ctx.handle, self.handle, i, desc.ctypes.data_as(C.c_void_p), coor.ctypes.data_as(C.c_void_p)))
+        return desc, coor
+
+    @classmethod
+    def from_host(cls, ctx, descs, coors=None):
+        n = len(descs)
+        descs = [np.ascontiguousarray(d, np.float32).reshape(-1, 128) for d in descs]
+        dp = (C.c_void_p * n)(*[d.ctypes.data_as(C.c_void_p) for d in descs])
+        if coors is not None:
+            coors = [np.ascontiguousarray(c, np.float64).reshape(-1, 2) for c in coors]
+            cp = (C.c_void_p * n)(*[c.ctypes.data_as(C.c_void_p) for c in coors])
+        else:
+            cp = None
+        counts = (C.c_int * n)(*[len(d) for d in descs])
+        h = C.c_void_p()
+        check(lib().op_features_from_host(ctx.handle, dp, cp, counts, n, C.byref(h)))
+        return cls(ctx, h)
+
+    def free(self):
+        if self.handle:
+            lib().op_features_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sift_batch(ctx: Context, cfg, images) -> Features:
+    arr, keep = _mk_images(images)
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(lib().op_sift_batch(ctx.handle, C.byref(ccfg), arr, len(images), C.byref(h)))
+    del keep
+    return Features(ctx, h)
+
+
+def sift_staged(ctx: Context, cfg, image, planes=True):
+    """Staged single-image run -> object with the same fields as tests' ``SiftStages``."""
+    L = lib()
+    arr, keep = _mk_images([image])
+    ccfg = OpConfig.from_config(cfg)
+    hd = C.c_void_p()
+    check(L.op_sift_staged(ctx.handle, C.byref(ccfg), arr, C.byref(hd)))
+
+    class Stages:
+        pass
+
+    st = Stages()
+    try:
+        h, w = C.c_int(), C.c_int()
+        L.op_sift_dump_working_dims(hd, C.byref(h), C.byref(w))
+        st.work = np.empty((h.value, w.value, 3), np.float32)
+        check(L.op_sift_dump_plane(ctx.handle, hd, 4, 0, 0, st.work.ctypes.data_as(C.c_void_p)))
+        st.dims = []; st.grey = {}; st.dog = {}; st.mag = {}; st.ort = {}; st.raw = {}
+        for o in range(cfg.NUM_OCTAVE):
+            check(L.op_sift_dump_octave_dims(hd, o, C.byref(h), C.byref(w)))
+            st.dims.append((h.value, w.value))
+            if planes:
+                def grab(kind, s):
+                    buf = np.empty((h.value, w.value), np.float32)
+                    check(L.op_sift_dump_plane(ctx.handle, hd, kind, o, s, buf.ctypes.data_as(C.c_void_p)))
+                    return buf
+                st.grey[o] = grab(5, 0)
+                for s in range(cfg.NUM_SCALE - 1):
+                    st.dog[(o, s)] = grab(1, s)
+                for s in range(1, cfg.NUM_SCALE - 2):
+                    st.mag[(o, s)] = grab(2, s)
+                    st.ort[(o, s)] = grab(3, s)
+            for s in range(1, cfg.NUM_SCALE - 2):
+                n = L.op_sift_dump_raw_count(hd, o, s)
+                xy = np.empty((n, 2), np.int32)
+                if n:
+                    L.op_sift_dump_raw(hd, o, s, xy.ctypes.data_as(C.c_void_p))
+                st.raw[(o, s)] = xy
+        for which, name in ((0, "refined"), (1, "oriented")):
+            n = L.op_sift_dump_kp_count(hd, which)
+            ints = np.empty((n, 4), np.int32); real = np.empty((n, 2), np.float64); fl = np.empty((n, 2), np.float32)
+            if n:
+                L.op_sift_dump_kp(hd, which, ints.ctypes.data_as(C.c_void_p), real.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p))
+            setattr(st, name, dict(ints=ints, real=real, fl=fl))
+        k = L.op_sift_dump_kp_count(hd, 1)
+        st.desc = np.empty((k, 128), np.float32); st.coor = np.empty((k, 2), np.float64)
+        if k:
+            L.op_sift_dump_desc(hd, st.desc.ctypes.data_as(C.c_void_p), st.coor.ctypes.data_as(C.c_void_p))
+    finally:
+        L.op_sift_dump_free(hd)
+    del keep
+    return st
+
+
+def debug_math(ctx: Context, which: int, x, y=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32) if y is not None else x
+    out = np.empty_like(x)
+    check(lib().op_debug_math(ctx.handle, which, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -70,6 +70,8 @@ float orc_expf_twin(float x);
 float orc_cosf_twin(float x);
 float orc_sinf_twin(float x);
 float orc_hypotf_twin(float x, float y);
+/* real libm / fast_atan over arrays: 0 expf, 1 cosf, 2 sinf, 3 hypotf(x,y), 4 fast_atan(y,x)+pi */
+void orc_libm_batch(int which, const float* x, const float* y, long n, float* out);
 
 /* ---- exact matcher: FeatureMatcher::match (feature/matcher.cc:15-71) ---- */
 float orc_euclidean_sqr(const float* x, const float* y, int n, float now_thres);	/* feature/dist.cc:22-57 */

@@ -669,3 +669,18 @@ long orc_calc_feature_batch(const orc_sift_cfg* cfg, const float* rgb, int n, in
 	}
 	return total;
 }
+
+/* libm (the real glibc calls the reference makes) and fast_atan over arrays: the GPU tests
+ * compare the device twins in openpano_amd/csrc/devmath.hpp against these on the same box.
+ * which: 0 expf, 1 cosf, 2 sinf, 3 hypotf(x,y), 4 fast_atan(y,x)+pi as stored by cal_mag_ort */
+void orc_libm_batch(int which, const float* x, const float* y, long n, float* out) {
+	for (long i = 0; i < n; ++i) {
+		switch (which) {
+			case 0: out[i] = expf(x[i]); break;
+			case 1: out[i] = cosf(x[i]); break;
+			case 2: out[i] = sinf(x[i]); break;
+			case 3: out[i] = hypotf(x[i], y[i]); break;
+			default: out[i] = (float)(fast_atan(y[i], x[i]) + M_PI); break;
+		}
+	}
+}

@@ -24,8 +24,8 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 
 
 def build_oracle():
-    if not os.path.exists(ORACLE_SO):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+    # make is a no-op when liboracle.so is newer than its sources
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
 
 class OrcCfg(C.Structure):
@@ -142,6 +142,7 @@ class Oracle(_StagedBase):
         for n in ("orc_expf_twin", "orc_cosf_twin", "orc_sinf_twin"):
             getattr(lib, n).restype = C.c_float; getattr(lib, n).argtypes = [C.c_float]
         lib.orc_hypotf_twin.restype = C.c_float; lib.orc_hypotf_twin.argtypes = [C.c_float, C.c_float]
+        lib.orc_libm_batch.argtypes = [C.c_int, _f32p, _f32p, C.c_long, _f32p]
         lib.orc_euclidean_sqr.restype = C.c_float
         lib.orc_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
         lib.orc_match_exact.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, _i32p]
@@ -175,6 +176,12 @@ class Oracle(_StagedBase):
         buf = np.zeros(128, np.float32)
         kw = self.lib.orc_gauss_kernel(self._cp(), np.float32(sigma), buf)
         return buf[:kw].copy()
+
+    def libm(self, which, x, y=None):
+        x = np.ascontiguousarray(x, np.float32); y = x if y is None else np.ascontiguousarray(y, np.float32)
+        out = np.empty_like(x)
+        self.lib.orc_libm_batch(which, x, y, x.size, out)
+        return out
 
     def match_exact(self, d1, d2):
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
