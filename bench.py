@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native OpenPano hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): SIFT keypoints+descriptors/sec (``value``) and all-pairs matches/sec
+(``match``) on BASELINE config 4 -- 38 unordered 1300x867 images -- restated as seeded synthetic
+views (openpano_amd/synth.py; the reference's example data needs the network).
+
+One step = one pass of the hot path over one batch: op_sift_batch over this rank's 38 images
+(inputs already resident in HBM), descriptors left in HBM.  A second timed loop measures the
+all-pairs exact match over the same descriptors (RCCL all-gather of descriptors first when N>1).
+Scaling is weak: every rank owns 38 images; the job is the unordered set of 38*N images.
+
+The JSON line also carries
+  roofline      live HIP-event timing of the dominant kernel vs its algorithmic HBM bytes,
+  cpu_baseline  the reference's CPU path (oracle/_ref when it travelled, else the C oracle) timed
+                on this box's host cores on a bounded sample of the same images (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def pyramid_pixels(cfg, h, w):
+    """P = sum of octave pixels for an h x w source (feature.cc:33-35, dog.cc:105-107)."""
+    ratio = np.float32(cfg.SIFT_WORKING_SIZE * 2.0) / np.float32(w + h)
+    wh, ww = int(np.float32(h) * ratio), int(np.float32(w) * ratio)
+    P = 0
+    for i in range(cfg.NUM_OCTAVE):
+        f = np.float32(np.float64(np.float32(cfg.SCALE_FACTOR)) ** (-i))
+        P += (int(np.ceil(np.float32(ww) * f)) * int(np.ceil(np.float32(wh) * f))) if i else wh * ww
+    return P, wh, ww
+
+
+def cpu_baseline(cfg, views, log):
+    """Reference CPU path on this box's host cores, bounded sample (~10-30 s of CPU work)."""
+    from checkers import Oracle, Ref, ref_available
+    cores = os.cpu_count() or 1
+    nsample = int(min(max(16, 2 * cores), 96))
+    sample = [views[i % len(views)] for i in range(nsample)]
+    kind = "port"
+    try:
+        if ref_available():
+            eng = Ref(cfg); kind = "reference"
+        else:
+            eng = Oracle(cfg)
+    except OSError as e:   # _ref built for another libstdc++/CPU: fall back to the C port
+        log(f"oracle/_ref unusable ({e}); using the C oracle")
+        eng = Oracle(cfg)
+    eng.calc_feature_batch(sample[:2], 1)                      # warm
+    t0 = time.perf_counter(); k1 = eng.calc_feature_batch(sample[:4], 1); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); kall = eng.calc_feature_batch(sample, cores); tall = time.perf_counter() - t0
+    return {
+        "value": kall / tall, "unit": "keypoints+descriptors/s", "cores": cores, "kind": kind,
+        "sample": f"{nsample} of the workload's 1300x867 views, {'OpenMP parallel-for over images like StitcherBase::calc_feature' } with {cores} threads; "
+                  f"wall {tall:.2f} s; single-thread rate {k1 / t1:.0f}/s on 4 views",
+        "single_thread_value": k1 / t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=38, help="images per rank (BASELINE config 4: 38)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    from openpano_amd import hip, synth
+    from openpano_amd.config import PanoConfig
+    cfg = PanoConfig()
+    H, W = 867, 1300
+    nimg = args.images
+    # rank r owns views [r*nimg, (r+1)*nimg) of one seeded unordered set (config 4 restated)
+    t0 = time.perf_counter()
+    views = synth.image_set(nimg, H, W, seed=38 + 1000 * rank, overlap=0.45, rows=2, shuffle=True)
+    log(f"synthetic views: {nimg} x {W}x{H} in {time.perf_counter() - t0:.1f} s")
+    dev = torch.device("cuda", local_rank)
+    d_imgs = [torch.from_numpy(v).to(dev) for v in views]         # inputs resident in HBM
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=dev)                         # the stream every kernel is launched on
+    torch.cuda.set_stream(stream)
+    ctx = hip.Context(local_rank, stream.cuda_stream)
+    inputs = [(t.data_ptr(), H, W) for t in d_imgs]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- SIFT loop ----------------
+    feats = None
+    for _ in range(args.warmup):
+        if feats is not None:
+            feats.free()
+        feats = hip.sift_batch(ctx, cfg, inputs)
+    ctx.set_profiling(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feats.free()
+        feats = hip.sift_batch(ctx, cfg, inputs)
+    barrier()
+    t_sift = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.set_profiling(False)
+    k_rank = int(feats.total)
+    tt = torch.tensor([t_sift, float(k_rank)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        t_sift_max, k_total = float(tmax[0]), int(tsum[1])
+    else:
+        t_sift_max, k_total = t_sift, k_rank
+    value = k_total * args.steps / t_sift_max
+
+    # ---------------- roofline of the dominant kernel (HIP events, this rank) ----------------
+    P, wh, ww = pyramid_pixels(cfg, H, W)
+    stage_ms = {k: v[0] / max(v[1], 1) for k, v in prof.items()}
+    dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
+    # algorithmic HBM bytes per launch (DESIGN.md "kernels"), per image:
+    alg = {
+        "build pyramid": 4 * P + 24 * P + 32 * P,                        # grey in, 6 DoG + 4 mag + 4 ort out
+        "extrema scan": 24 * P,                                          # the 6 DoG planes once
+        "resize": 12 * H * W + 12 * wh * ww,
+        "octave grey": 12 * wh * ww + 4 * P,
+        "sift descriptor": (k_rank / nimg) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
+        "orientation": (k_rank / nimg) * (8 * 16 * 16),
+    }
+    roofline = None
+    if dominant is not None:
+        b = alg.get(dominant)
+        dur_s = stage_ms[dominant] * 1e-3
+        ach = (b * nimg / dur_s / 1e9) if b else None
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": b * nimg if b else None, "avg_launch_ms": stage_ms[dominant]}
+    # whole SIFT path against SURVEY 8(d): 12WH + 88P + G + 528K per image
+    G = (k_rank / nimg) * 8 * (16 * 16 + 37 * 37)
+    b_path = nimg * (12 * H * W + 88 * P + G + 528 * (k_rank / nimg))
+    path_gbs = b_path * args.steps / t_sift / 1e9
+
+    out = {
+        "metric": "SIFT keypoints+desc/sec and all-pairs matches/sec at 1/2/4/8 GPUs",
+        "value": value, "unit": "keypoints+descriptors/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_sift_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 4 restated: {nimg} unordered {W}x{H} views per GPU (x{args.gpus} GPUs), "
+                               "default config.cfg, inputs resident in HBM",
+                   "images_per_gpu": nimg, "image": [H, W], "keypoints_per_image": k_total / (nimg * args.gpus),
+                   "parallelism": f"images sharded {nimg}/GPU x {args.gpus}"},
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "roofline": roofline,
+        "sift_path_roofline": {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": b_path},
+    }
+
+    # ---------------- all-pairs match loop ----------------
+    if hasattr(hip, "match_pairs") and not args.no_match:
+        from bench_match import run_match_loop
+        out["match"] = run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, log)
+
+    # ---------------- CPU baseline (rank 0, N=1 only) ----------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        out["cpu_baseline"] = cpu_baseline(cfg, views, log)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        log(f"cpu baseline took {time.perf_counter() - t0:.1f} s")
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    feats.free()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

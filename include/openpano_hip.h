@@ -72,6 +72,13 @@ typedef struct op_ctx op_ctx;
 int op_ctx_create(int device, void* hip_stream, op_ctx** out);
 void op_ctx_destroy(op_ctx* ctx);
 int op_ctx_sync(op_ctx* ctx);
+/* Per-stage device timing with HIP events on the context's stream -- the counterpart of the
+ * reference's TotalTimer table (lib/timer.hh:63-83, dumped at exit by main.cc:336); stage labels
+ * reuse the reference's ("build pyramid", "extrema", "sift descriptor", "matcher", ...). */
+int op_ctx_set_profiling(op_ctx* ctx, int enable);
+int op_ctx_profile_reset(op_ctx* ctx);
+int op_ctx_profile_count(op_ctx* ctx);
+int op_ctx_profile_get(op_ctx* ctx, int i, const char** label, double* total_ms, long* calls);
 
 typedef struct op_image {
 	const float* data;   /* H x W x 3 fp32 */

@@ -5,7 +5,58 @@
 static thread_local std::string g_last_error;
 void op_set_error(const std::string& msg) { g_last_error = msg; }
 
+static hipEvent_t take_event(op_ctx* c) {
+	if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
+ProfScope::ProfScope(op_ctx* ctx, const char* label): c(ctx) {
+	if (!c->profiling) return;
+	stage = c->prof_stage(label);
+	a = take_event(c); b = take_event(c);
+	if (a) hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+	if (stage < 0 || !a || !b) return;
+	hipEventRecord(b, c->stream);
+	c->pending.push_back({stage, a, b});
+}
+void resolve_profile(op_ctx* c) {
+	for (auto& p : c->pending) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->prof[p.stage].total_ms += ms; c->prof[p.stage].calls += 1; }
+		c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+	}
+	c->pending.clear();
+}
+
 extern "C" {
+
+int op_ctx_set_profiling(op_ctx* c, int enable) {
+	if (!c) OP_FAIL(OP_ERR_INVALID, "op_ctx_set_profiling: NULL context");
+	c->profiling = enable != 0;
+	return OP_OK;
+}
+int op_ctx_profile_reset(op_ctx* c) {
+	if (!c) OP_FAIL(OP_ERR_INVALID, "op_ctx_profile_reset: NULL context");
+	HIPCHK(hipStreamSynchronize(c->stream));
+	resolve_profile(c);
+	c->prof.clear();
+	return OP_OK;
+}
+int op_ctx_profile_count(op_ctx* c) {
+	if (!c) return 0;
+	if (hipStreamSynchronize(c->stream) == hipSuccess) resolve_profile(c);
+	return (int)c->prof.size();
+}
+int op_ctx_profile_get(op_ctx* c, int i, const char** label, double* total_ms, long* calls) {
+	if (!c || i < 0 || i >= (int)c->prof.size()) OP_FAIL(OP_ERR_INVALID, "op_ctx_profile_get: bad index");
+	if (label) *label = c->prof[i].label.c_str();
+	if (total_ms) *total_ms = c->prof[i].total_ms;
+	if (calls) *calls = c->prof[i].calls;
+	return OP_OK;
+}
 
 const char* op_last_error(void) { return g_last_error.c_str(); }
 int op_abi_version(void) { return 1; }
@@ -52,6 +103,8 @@ void op_ctx_destroy(op_ctx* c) {
 	hipSetDevice(c->device);
 	hipStreamSynchronize(c->stream);
 	op_ctx_release_workspace(c);
+	resolve_profile(c);
+	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
 	if (c->owns_stream) hipStreamDestroy(c->stream);
 	delete c;
 }

@@ -5,34 +5,44 @@
 // (feature/feature.cc:20-28).
 //
 // Bit-exactness: the reference accumulates hist[bin] += w in window order (xx outer, yy inner)
-// in fp32, so the summation order is part of the result.  Samples are therefore evaluated 64 at
-// a time (all lanes), compacted in order into LDS, and then every histogram bin is accumulated
-// by exactly one lane walking the samples in that order (lane l owns bins l and l+64: cell
-// l>>2 (+0), orientation bins (l&3) and (l&3)+4 ... see below).
+// in fp32, so the summation ORDER is part of the result.  Structure per keypoint:
+//   1a  all 64 lanes test window samples (bounds, circle, rotated bin range), 64 per round;
+//   1b  surviving samples are compacted IN ORDER into LDS records (weights of the 2x2 spatial
+//       cells, orientation fraction) -- the expensive part (expf, gathers) runs on survivors only;
+//   1c  per spatial cell an ordered list of the records that touch it is built with wave
+//       ballots (16 ballots per 64 records);
+//   2   lane (cell, hj) walks its cell's list in order and adds the record's contribution to
+//       the orientation bins hj and hj+4 it owns.  A non-matching orientation adds +0.0f, which
+//       is exact, so every bin sees exactly the reference's sequence of fp32 additions.
+// Records are flushed through 1c/2 whenever an LDS buffer would overflow, so any window size
+// is handled with the same ordering guarantee.
 #include "internal.hpp"
 #include "devmath.hpp"
 
 namespace {
 
-constexpr int DESC_CHUNK = 512;      // window samples staged per pass
+constexpr int REC_CAP = 512;         // records (surviving samples) buffered per flush
+constexpr int LIST_CAP = 256;        // entries per spatial-cell list per flush
 
-struct SampleRec {                   // one window sample that passed every test (sift.cc:110-128)
-	float w00, w01, w10, w11;        // weight * {1-ybind, ybind} * {1-xbind, xbind}  (w_x of :61)
-	float hbind;                     // fractional orientation bin
-	int packed;                      // (ybinf+1) | (xbinf+1) << 4 | (hbinf & 15) << 8
+struct DescLds {
+	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
+	float hb[REC_CAP];               // hbind
+	float omh[REC_CAP];              // 1 - hbind
+	unsigned short list[16][LIST_CAP];   // entry = record | u << 9 | h0 << 11
+	int len[16];
+	float hist[128];
 };
 
-// lane l owns spatial cell (l >> 2) and the two orientation bins (l & 3) and (l & 3) + 4
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
 		const long long* img_offset, long long total, float* desc, double* coor) {
-	__shared__ SampleRec s_rec[DESC_CHUNK];
-	__shared__ int s_count;
-	__shared__ float s_hist[128];
+	__shared__ DescLds S;
 	const int lane = threadIdx.x;
+	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 	const float pi2 = (float)(2 * 3.14159265358979323846);
 	const float nbin_per_rad = 8 / pi2;
+	const int cell = lane >> 2, hj = lane & 3;
+
 	for (long long kk = blockIdx.x; kk < total; kk += gridDim.x) {
-		// image of this keypoint: img_offset is a short ascending table
 		int img = 0;
 		while (img + 1 < p.n && kk >= img_offset[img + 1]) ++img;
 		const KeyPoint kp = oriented[kk];
@@ -48,89 +58,117 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		const float cosort = opdev::cosf_glibc(ort), sinort = opdev::sinf_glibc(ort);
 		const int side = 2 * radius + 1, nsamp = side * side;
 		const float fr2 = (float)radius * (float)radius;
-		const int cell = lane >> 2, by = cell >> 2, bx = cell & 3, hj = lane & 3;
 		float acc0 = 0.f, acc1 = 0.f;     // bins (cell, hj) and (cell, hj + 4)
+		int nrec = 0;                     // records buffered (wave-uniform)
+		int len[16];                      // list lengths (wave-uniform)
+#pragma unroll
+		for (int c = 0; c < 16; ++c) len[c] = 0;
+		int maxlen = 0;
 
-		for (int cb = 0; cb < nsamp; cb += DESC_CHUNK) {
-			if (lane == 0) s_count = 0;
-			__syncthreads();
-			// phase 1: evaluate up to DESC_CHUNK window samples, ordered compaction into s_rec
-			for (int i0 = 0; i0 < DESC_CHUNK && cb + i0 < nsamp; i0 += 64) {
-				const int e = cb + i0 + lane;
-				bool ok = false;
-				SampleRec rec;
-				if (e < nsamp && i0 + lane < DESC_CHUNK) {
-					const int xx = e / side - radius, yy = e % side - radius;
-					const int nowx = kp.x + xx, nowy = kp.y + yy;
-					if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
-						const float fxx = (float)xx, fyy = (float)yy;
-						if (!(fxx * fxx + fyy * fyy > fr2)) {
-							const float y_rot = ((float)(-xx) * sinort + fyy * cosort) / hist_w;
-							const float x_rot = (fxx * cosort + fyy * sinort) / hist_w;
-							const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
-							// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
-							if (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f) {
-								const long long gi = (long long)nowy * w + nowx;
-								const float now_mag = mag_img[gi];
-								float now_ort = ort_img[gi];
-								float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom);
-								weight = weight * now_mag;
-								now_ort -= ort;
-								if (now_ort < 0) now_ort += pi2;
-								if (now_ort > pi2) now_ort -= pi2;
-								const float hbin = now_ort * nbin_per_rad;
-								// trilinear_interpolate (:48-67)
-								const float yf = floorf(ybin), xf = floorf(xbin), hf = floorf(hbin);
-								const int ybinf = (int)yf, xbinf = (int)xf, hbinf = (int)hf;
-								const float ybind = ybin - (float)ybinf, xbind = xbin - (float)xbinf;
-								const float wy0 = weight * (1 - ybind), wy1 = weight * ybind;
-								rec.w00 = wy0 * (1 - xbind); rec.w01 = wy0 * xbind;
-								rec.w10 = wy1 * (1 - xbind); rec.w11 = wy1 * xbind;
-								rec.hbind = hbin - (float)hbinf;
-								rec.packed = (ybinf + 1) | ((xbinf + 1) << 4) | ((hbinf & 15) << 8);
-								ok = true;
-							}
-						}
-					}
-				}
-				const unsigned long long mask = __ballot(ok);
-				const int basec = s_count;
-				if (ok) s_rec[basec + __popcll(mask & ((1ULL << lane) - 1ULL))] = rec;
-				__syncthreads();
-				if (lane == 0) s_count = basec + __popcll(mask);
-				__syncthreads();
+		auto flush = [&]() {
+			// phase 2: ordered accumulation from the cell lists
+			if (lane < 16) {
+				int v = 0;
+#pragma unroll
+				for (int c = 0; c < 16; ++c) v = (lane == c) ? len[c] : v;
+				S.len[lane] = v;
 			}
-			// phase 2: each lane folds the samples, in order, into the bins it owns
-			const int cnt = s_count;
-			for (int i = 0; i < cnt; ++i) {
-				const SampleRec r = s_rec[i];
-				const int dy = by - ((r.packed & 15) - 1), dx = bx - (((r.packed >> 4) & 15) - 1);
-				if ((unsigned)dy < 2u && (unsigned)dx < 2u) {
-					const float wx = dy ? (dx ? r.w11 : r.w10) : (dx ? r.w01 : r.w00);
-					const int hb = (r.packed >> 8) & 15;        // hbinf in 0..8
-					const int h0 = hb & 7, h1 = (hb + 1) & 7;   // hbinf % 8, (hbinf + 1) % 8
-					if ((h0 & 3) == hj) {
-						const float v = wx * (1 - r.hbind);
-						if (h0 >> 2) acc1 += v; else acc0 += v;
-					} else if ((h1 & 3) == hj) {
-						const float v = wx * r.hbind;
-						if (h1 >> 2) acc1 += v; else acc0 += v;
-					}
+			__syncthreads();
+			const int mylen = S.len[cell];
+			const unsigned short* mylist = S.list[cell];
+#pragma unroll 4
+			for (int t = 0; t < maxlen; ++t) {
+				if (t < mylen) {
+					const unsigned e = mylist[t];
+					const int ridx = e & 511, u = (e >> 9) & 3, h0 = (e >> 11) & 7;
+					const float wx = S.w[u][ridx];
+					const int d = (hj - h0) & 3;
+					const float factor = d ? S.hb[ridx] : S.omh[ridx];
+					const float v = wx * factor;               // sift.cc:63-64
+					const float c = d < 2 ? v : 0.f;           // + 0.0f is exact
+					const int hi = ((h0 + d) >> 2) & 1;        // bin hbinf%8 / (hbinf+1)%8 in upper half?
+					acc0 += hi ? 0.f : c;
+					acc1 += hi ? c : 0.f;
 				}
 			}
 			__syncthreads();
+			nrec = 0; maxlen = 0;
+#pragma unroll
+			for (int c = 0; c < 16; ++c) len[c] = 0;
+		};
+
+		for (int i0 = 0; i0 < nsamp; i0 += 64) {
+			// flush first if this round could overflow a buffer
+			if (nrec + 64 > REC_CAP || maxlen + 64 > LIST_CAP) flush();
+			// phase 1a: cheap tests
+			const int e = i0 + lane;
+			bool ok = false;
+			int xx = 0, yy = 0;
+			float x_rot = 0.f, y_rot = 0.f, xbin = 0.f, ybin = 0.f;
+			long long gi = 0;
+			if (e < nsamp) {
+				xx = e / side - radius; yy = e % side - radius;
+				const int nowx = kp.x + xx, nowy = kp.y + yy;
+				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
+					const float fxx = (float)xx, fyy = (float)yy;
+					if (!(fxx * fxx + fyy * fyy > fr2)) {
+						y_rot = ((float)(-xx) * sinort + fyy * cosort) / hist_w;
+						x_rot = (fxx * cosort + fyy * sinort) / hist_w;
+						ybin = (y_rot + 2.f) - 0.5f; xbin = (x_rot + 2.f) - 0.5f;
+						// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
+						ok = (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f);
+						gi = (long long)nowy * w + nowx;
+					}
+				}
+			}
+			// phase 1b: ordered compaction + the expensive per-sample work on survivors
+			const unsigned long long mask = __ballot(ok);
+			const int ridx = nrec + __popcll(mask & lt_mask);
+			int yb = -9, xb = -9, h0 = 0;
+			if (ok) {
+				const float now_mag = mag_img[gi];
+				float now_ort = ort_img[gi];
+				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom);
+				weight = weight * now_mag;
+				now_ort -= ort;
+				if (now_ort < 0) now_ort += pi2;
+				if (now_ort > pi2) now_ort -= pi2;
+				const float hbin = now_ort * nbin_per_rad;
+				const float yf = floorf(ybin), xf = floorf(xbin), hf = floorf(hbin);
+				yb = (int)yf; xb = (int)xf; h0 = ((int)hf) & 7;     // hbinf % 8 (hbinf in 0..8)
+				const float ybind = ybin - yf, xbind = xbin - xf, hbind = hbin - hf;
+				const float wy0 = weight * (1 - ybind), wy1 = weight * ybind;
+				S.w[0][ridx] = wy0 * (1 - xbind); S.w[1][ridx] = wy0 * xbind;
+				S.w[2][ridx] = wy1 * (1 - xbind); S.w[3][ridx] = wy1 * xbind;
+				S.hb[ridx] = hbind; S.omh[ridx] = 1 - hbind;
+			}
+			nrec += __popcll(mask);
+			// phase 1c: ordered per-cell lists
+			if (mask) {
+#pragma unroll
+				for (int c = 0; c < 16; ++c) {
+					const int dy = (c >> 2) - yb, dx = (c & 3) - xb;
+					const bool touch = ok && (unsigned)dy < 2u && (unsigned)dx < 2u;
+					const unsigned long long m = __ballot(touch);
+					if (touch) S.list[c][len[c] + __popcll(m & lt_mask)] = (unsigned short)(ridx | ((dy * 2 + dx) << 9) | (h0 << 11));
+					len[c] += __popcll(m);
+					maxlen = len[c] > maxlen ? len[c] : maxlen;
+				}
+			}
 		}
+		flush();
+
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
-		s_hist[cell * 8 + hj] = acc0;
-		s_hist[cell * 8 + hj + 4] = acc1;
+		S.hist[cell * 8 + hj] = acc0;
+		S.hist[cell * 8 + hj + 4] = acc1;
 		__syncthreads();
 		float sum = 0.f;
-		for (int i = 0; i < 128; ++i) sum += s_hist[i];
+		for (int i = 0; i < 128; ++i) sum += S.hist[i];
 		float* out = desc + kk * 128;
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {
 			const int i = lane + 64 * t;
-			const float v = s_hist[i] / sum;
+			const float v = S.hist[i] / sum;
 			out[i] = sqrtf(v) * (float)p.desc_int_factor;
 		}
 		if (lane == 0) {   // feature/feature.cc:23-26
@@ -146,7 +184,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset,
 		long long total, float* desc, double* coor, hipStream_t st) {
 	if (total <= 0) return hipSuccess;
-	const int grid = (int)(total < 16384 ? total : 16384);
+	const int grid = (int)(total < 32768 ? total : 32768);
 	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, total, desc, coor);
 	return hipGetLastError();
 }

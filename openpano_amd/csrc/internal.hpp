@@ -17,11 +17,31 @@ void op_ctx_release_workspace(op_ctx* c);
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return OP_ERR_HIP; } } while (0)
 
+// per-stage device timing (HIP events on the context's stream), the counterpart of the
+// reference's TotalTimer table (lib/timer.hh:63-83); labels reuse the reference's where one exists
+struct ProfStage { std::string label; double total_ms = 0; long calls = 0; };
 struct op_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool owns_stream = false;
+	bool profiling = false;
+	std::vector<ProfStage> prof;
+	std::vector<hipEvent_t> ev_pool;                 // recycled events
+	struct Pending { int stage; hipEvent_t a, b; };
+	std::vector<Pending> pending;                    // recorded, not yet resolved
+	int prof_stage(const std::string& label) {
+		for (size_t i = 0; i < prof.size(); ++i) if (prof[i].label == label) return (int)i;
+		prof.push_back(ProfStage{label, 0, 0});
+		return (int)prof.size() - 1;
+	}
 };
+// RAII bracket around one stage's launches; resolve_profile() after a stream sync
+struct ProfScope {
+	op_ctx* c; int stage = -1; hipEvent_t a = nullptr, b = nullptr;
+	ProfScope(op_ctx* ctx, const char* label);
+	~ProfScope();
+};
+void resolve_profile(op_ctx* c);
 
 // ---------------------------------------------------------------------------------------
 // HBM layout of one image's scale space ("image workspace", ws_stride floats per image):

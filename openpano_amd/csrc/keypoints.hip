@@ -229,23 +229,48 @@ __device__ __forceinline__ bool kp_less(const KeyPoint& a, const KeyPoint& b) {
 	return false;
 }
 
-// rank sort, one workgroup per image (K is ~1e3; O(K^2) comparisons on 256 lanes)
+// Rank sort into the canonical order.  Grid (cap/256, n): every thread ranks one keypoint of
+// its image against all K keypoints, whose packed 64-bit primary keys (oct, scale, y, x) are
+// staged through LDS in chunks; the full comparison only runs on primary-key ties.
+__device__ __forceinline__ unsigned long long kp_key(const KeyPoint& k) {
+	return ((unsigned long long)(unsigned)k.oct << 48) | ((unsigned long long)(unsigned)k.scale << 40) |
+		((unsigned long long)(unsigned)(k.y & 0xFFFFF) << 20) | (unsigned long long)(unsigned)(k.x & 0xFFFFF);
+}
+constexpr int SORT_CHUNK = 2048;
 __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const int* count, int cap, KeyPoint* out) {
-	const int img = blockIdx.x;
+	__shared__ unsigned long long s_key[SORT_CHUNK];
+	const int img = blockIdx.y;
 	const int n = count[img];
+	if ((int)(blockIdx.x * 256) >= n) return;
 	const KeyPoint* a = in + (long long)img * cap;
 	KeyPoint* b = out + (long long)img * cap;
-	for (int i = threadIdx.x; i < n; i += 256) {
-		const KeyPoint me = a[i];
-		int rank = 0;
-		for (int j = 0; j < n; ++j) {
-			const KeyPoint& o = a[j];
-			// fully identical records tie-break on the slot index: any assignment is the same output
-			rank += (kp_less(o, me) || (!kp_less(me, o) && j < i)) ? 1 : 0;
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const bool live = i < n;
+	KeyPoint me;
+	if (live) me = a[i];
+	const unsigned long long mykey = live ? kp_key(me) : 0ULL;
+	int rank = 0;
+	for (int cb = 0; cb < n; cb += SORT_CHUNK) {
+		const int cn = n - cb < SORT_CHUNK ? n - cb : SORT_CHUNK;
+		__syncthreads();
+		for (int j = threadIdx.x; j < cn; j += 256) s_key[j] = kp_key(a[cb + j]);
+		__syncthreads();
+		if (live) {
+			for (int j = 0; j < cn; ++j) {
+				const unsigned long long kj = s_key[j];
+				if (kj < mykey) ++rank;
+				else if (kj == mykey) {
+					const int gj = cb + j;
+					if (gj != i) {
+						const KeyPoint o = a[gj];
+						// identical records tie-break on the slot index: either assignment is the same output
+						rank += (kp_less(o, me) || (!kp_less(me, o) && gj < i)) ? 1 : 0;
+					}
+				}
+			}
 		}
-		KeyPoint w = me; w.src = rank;
-		b[rank] = w;
 	}
+	if (live) { me.src = rank; b[rank] = me; }
 }
 
 // ---- OrientationAssign::calc_dir (feature/orientation.cc:34-100): one wavefront per keypoint.
@@ -408,7 +433,7 @@ hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count
 
 hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
 		KeyPoint* out, hipStream_t st) {
-	hipLaunchKernelGGL(k_sort_refined, dim3(p.n), dim3(256), 0, st, in, count, cap, out);
+	hipLaunchKernelGGL(k_sort_refined, dim3((cap + 255) / 256, p.n), dim3(256), 0, st, in, count, cap, out);
 	return hipGetLastError();
 }
 

@@ -202,14 +202,16 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	int* d_oriented_count = d_raw_count + 2 * n;
 	HIPCHK(hipMemsetAsync(W.counts.p, 0, sizeof(int) * 4 * n, st));
 
-	HIPCHK(launch_resize_to_work(plan, st));
-	HIPCHK(launch_octave_grey(plan, st));
-	HIPCHK(launch_pyramid(plan, st));
-	HIPCHK(launch_extrema_scan(plan, (int*)W.raw.p, d_raw_count, cap, st));
-	HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
-	HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st));
-	HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, st));
-	HIPCHK(launch_count_oriented(plan, d_refined_count, cap, (const int*)W.ndirs.p, d_oriented_count, st));
+	{ ProfScope ps(ctx, "resize"); HIPCHK(launch_resize_to_work(plan, st)); }
+	{ ProfScope ps(ctx, "octave grey"); HIPCHK(launch_octave_grey(plan, st)); }
+	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, st)); }
+	{ ProfScope ps(ctx, "extrema scan"); HIPCHK(launch_extrema_scan(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
+	{ ProfScope ps(ctx, "extrema refine");
+	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
+	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st)); }
+	{ ProfScope ps(ctx, "orientation");
+	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, st));
+	  HIPCHK(launch_count_oriented(plan, d_refined_count, cap, (const int*)W.ndirs.p, d_oriented_count, st)); }
 
 	// pinned scratch regions: [0,8n) source table | [16n,28n) counts | [32n, 40n+8) offsets
 	int* h_counts = (int*)((char*)W.pinned + 16 * (size_t)n);
@@ -231,10 +233,13 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)std::max<long long>(total, 1)));
 	HIPCHK(hipMalloc(&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
 	HIPCHK(hipMalloc(&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
-				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st));
-	HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, st));
+	{ ProfScope ps(ctx, "orientation");
+	  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
+				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st)); }
+	{ ProfScope ps(ctx, "sift descriptor");
+	  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, st)); }
 	HIPCHK(hipStreamSynchronize(st));     // h_off (pinned) consumed; results ready
+	resolve_profile(ctx);
 
 	if (keep) {
 		keep->cap = cap;

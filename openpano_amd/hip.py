@@ -93,6 +93,10 @@ def lib():
     L.op_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.op_ctx_destroy.argtypes = [C.c_void_p]
     L.op_ctx_sync.argtypes = [C.c_void_p]
+    L.op_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.op_ctx_profile_reset.argtypes = [C.c_void_p]
+    L.op_ctx_profile_count.argtypes = [C.c_void_p]
+    L.op_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.op_sift_batch.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_num_images.argtypes = [C.c_void_p]
     L.op_features_count.argtypes = [C.c_void_p, C.c_int]
@@ -144,6 +148,21 @@ class Context:
 
     def sync(self):
         check(lib().op_ctx_sync(self.handle))
+
+    def set_profiling(self, enable=True):
+        check(lib().op_ctx_set_profiling(self.handle, int(enable)))
+
+    def profile_reset(self):
+        check(lib().op_ctx_profile_reset(self.handle))
+
+    def profile(self):
+        """{stage label: (total_ms, calls)} measured with HIP events on this context's stream"""
+        out = {}
+        for i in range(lib().op_ctx_profile_count(self.handle)):
+            lab = C.c_char_p(); ms = C.c_double(); calls = C.c_long()
+            check(lib().op_ctx_profile_get(self.handle, i, C.byref(lab), C.byref(ms), C.byref(calls)))
+            out[lab.value.decode()] = (ms.value, calls.value)
+        return out
 
     def close(self):
         if self.handle:
