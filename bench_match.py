@@ -1,0 +1,72 @@
+"""All-pairs matching loop of bench.py (second metric of BASELINE.json: matches/sec).
+
+N = 1: the 703 unordered pairs of this rank's 38 images.
+N > 1: descriptors are all-gathered over RCCL/xGMI (variable sizes: counts first, then padded
+payload), every rank rebuilds the global image-indexed feature table in its HBM and matches an
+interleaved 1/N share of the global unordered pair list (stitcher.cc:100 partitioned by rank).
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, log):
+    nloc = feats.num_images
+    counts = [feats.count(i) for i in range(nloc)]
+    gather_ms = None
+    if world > 1:
+        from openpano_amd.distributed import allgather_descriptors
+        total = int(feats.total)
+        # zero-copy torch view of the library-owned descriptor buffer (same HIP runtime)
+        dloc = torch.as_tensor(feats.desc_device_array(), device=dev) if total else torch.zeros((0, 128), device=dev)
+        allgather_descriptors(dloc, counts)                              # warm-up (RCCL init)
+        barrier()
+        t0 = time.perf_counter()
+        glob, all_counts = allgather_descriptors(dloc, counts)
+        barrier()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        gfeats = hip.Features.from_device(ctx, glob.data_ptr(), all_counts)
+        nglob = len(all_counts)
+    else:
+        gfeats = feats
+        nglob = nloc
+        all_counts = counts
+    pairs = [(i, j) for i in range(nglob) for j in range(i + 1, nglob)]
+    from openpano_amd.distributed import partition_pairs
+    mine = partition_pairs(pairs, rank, world, all_counts if world > 1 else None)
+    flops = sum(2.0 * 128 * all_counts[i] * all_counts[j] for i, j in mine)
+    m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up
+    nmatch = sum(len(x) for x in m)
+    ctx.set_profiling(True); ctx.profile_reset()
+    steps = max(1, min(args.steps, 10))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hip.match_pairs(ctx, cfg, gfeats, mine)
+    barrier()
+    t = time.perf_counter() - t0
+    prof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith("matcher")}
+    ctx.set_profiling(False)
+    tt = torch.tensor([t], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(len(mine)), float(nmatch), flops], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    tmax = float(tt[0]); npairs, nm, fl = (float(x) for x in agg)
+    mfma_ms = prof.get("matcher mfma top4")
+    # both directions are ranked on the MFMA: 2 x (2*128*Ki*Kj) flop per unordered pair
+    res = {
+        "image_pairs_per_s": npairs * steps / tmax, "matches_per_s": nm * steps / tmax,
+        "image_pairs": int(npairs), "matches": int(nm), "steps": steps, "ms_per_step": tmax / steps * 1e3,
+        "descriptor_allgather_ms": gather_ms, "stage_ms": {k: round(v, 4) for k, v in prof.items()},
+        "roofline": None,
+    }
+    if mfma_ms:
+        ach = 2.0 * flops / (mfma_ms * 1e-3) / 1e12      # this rank's share, this rank's kernel time
+        res["roofline"] = {"kernel": "matcher mfma top4", "bound": "mfma", "achieved": ach, "peak": 157.3,
+                           "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                           "algorithmic_flop_per_launch": 2.0 * flops, "avg_launch_ms": mfma_ms}
+    if gfeats is not feats:
+        gfeats.free()
+    return res

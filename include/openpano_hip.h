@@ -112,6 +112,10 @@ int op_features_copy(op_ctx* ctx, const op_features* f, int i, float* desc, doub
 /* build an op_features from host arrays (debug commands / tests: match without SIFT) */
 int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* const* coor,
 		const int* counts, int n, op_features** out);
+/* the same from a flat DEVICE buffer (images back to back; D2D copy) -- the multi-GPU path hands
+ * the all-gathered descriptors of every rank's images to the matcher this way */
+int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev,
+		const int* counts, int n, op_features** out);
 void op_features_free(op_features* f);
 
 /* Staged single-image run keeping every intermediate (the debug commands raw_extrema /

@@ -64,6 +64,11 @@ struct op_features {
 	int device = 0;
 };
 
+struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
+FeatView op_features_view(const op_features* f) {
+	return FeatView{f->n, f->counts.data(), f->offsets.data(), f->desc, f->device};
+}
+
 struct op_sift_dump {
 	Workspace w;                       // private workspace kept alive for plane reads
 	SiftPlan plan;
@@ -352,6 +357,25 @@ int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* c
 		HIPCHK(hipMemcpyAsync(f->desc + f->offsets[i] * 128, desc[i], sizeof(float) * 128 * counts[i], hipMemcpyHostToDevice, ctx->stream));
 		if (coor && coor[i]) HIPCHK(hipMemcpyAsync(f->coor + f->offsets[i] * 2, coor[i], sizeof(double) * 2 * counts[i], hipMemcpyHostToDevice, ctx->stream));
 	}
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	*out = f;
+	return OP_OK;
+}
+
+int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev, const int* counts, int n, op_features** out) {
+	if (!ctx || !desc_dev || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_from_device: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	op_features* f = new op_features;
+	f->n = n; f->counts.assign(counts, counts + n); f->offsets.assign(n + 1, 0); f->device = ctx->device;
+	int64_t total = 0;
+	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
+	f->offsets[n] = total;
+	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
+	HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * cnt));
+	HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * cnt));
+	if (total) HIPCHK(hipMemcpyAsync(f->desc, desc_dev, sizeof(float) * 128 * total, hipMemcpyDeviceToDevice, ctx->stream));
+	if (coor_dev && total) HIPCHK(hipMemcpyAsync(f->coor, coor_dev, sizeof(double) * 2 * total, hipMemcpyDeviceToDevice, ctx->stream));
+	else HIPCHK(hipMemsetAsync(f->coor, 0, sizeof(double) * 2 * cnt, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	*out = f;
 	return OP_OK;

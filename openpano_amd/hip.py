@@ -110,6 +110,7 @@ def lib():
     L.op_features_coor_device.argtypes = [C.c_void_p]
     L.op_features_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.op_features_from_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_features_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_free.argtypes = [C.c_void_p]
     L.op_sift_staged.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.POINTER(C.c_void_p)]
     L.op_sift_dump_free.argtypes = [C.c_void_p]
@@ -243,6 +244,26 @@ class Features:
         check(lib().op_features_from_host(ctx.handle, dp, cp, counts, n, C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def from_device(cls, ctx, desc_ptr, counts, coor_ptr=None):
+        """flat device buffer (images back to back, total x 128 fp32) -> Features (D2D copy)"""
+        n = len(counts)
+        cc = (C.c_int * n)(*[int(c) for c in counts])
+        h = C.c_void_p()
+        check(lib().op_features_from_device(ctx.handle, C.c_void_p(int(desc_ptr)), C.c_void_p(int(coor_ptr)) if coor_ptr else None, cc, n, C.byref(h)))
+        return cls(ctx, h)
+
+    def desc_device_array(self):
+        """object exposing ``__cuda_array_interface__`` over the device descriptor buffer
+        (zero-copy view for torch.as_tensor(..., device='cuda'); valid while self is alive)"""
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (int(self.total), 128), "typestr": "<f4",
+                                      "data": (int(self.desc_ptr or 0), False), "version": 2, "strides": None}
+        v._owner = self
+        return v
+
     def free(self):
         if self.handle:
             lib().op_features_free(self.handle)
@@ -323,4 +344,25 @@ def debug_math(ctx: Context, which: int, x, y=None):
     y = np.ascontiguousarray(y, np.float32) if y is not None else x
     out = np.empty_like(x)
     check(lib().op_debug_math(ctx.handle, which, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def match_pairs(ctx: Context, cfg, feats: Features, pairs):
+    """All requested image pairs in one call -> list of (M, 2) int32 arrays of
+    <idx in image i, idx in image j>, sorted by (first, second) (``MatchData``, matcher.hh:14-25)."""
+    L = lib()
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(L.op_match_pairs(ctx.handle, C.byref(ccfg), feats.handle, pr.ctypes.data_as(C.c_void_p), len(pr), C.byref(h)))
+    out = []
+    try:
+        for p in range(len(pr)):
+            n = L.op_matches_count(h, p)
+            a = np.empty((n, 2), np.int32)
+            if n:
+                check(L.op_matches_copy(h, p, a.ctypes.data_as(C.c_void_p)))
+            out.append(a)
+    finally:
+        L.op_matches_free(h)
     return out
