@@ -156,7 +156,36 @@ int op_matches_count(const op_matches* m, int p);
 /* pairs of <idx in image i, idx in image j> sorted by (first, second) (MatchData, matcher.hh:14-25) */
 int op_matches_copy(const op_matches* m, int p, int* idx_pairs);
 int64_t op_matches_total(const op_matches* m);
+/* wrap host match lists (npairs lists of counts[p] <first, second> pairs): debug / test entry */
+int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out);
 void op_matches_free(op_matches* m);
+
+/* =====================================================================================
+ * RANSAC -- replaces TransformEstimation(...).get_transform(MatchInfo*)
+ * (stitch/transform_estimate.hh:22-31, transform_estimate.cc:26-218) for every pair at once.
+ * pairs / m must be the pair list and result of op_match_pairs (match p belongs to pairs[p]);
+ * keypoint coordinates come from f (centred original-image pixels); shapes_wh holds (w, h) of
+ * every image of f (Shape2D, stitch/match_info.hh:53-78).
+ * Homography (8-point samples) unless cfg->CYLINDER || cfg->TRANS (affine, 7-point samples).
+ * Sampling is std::mt19937 with the reference's duplicate rejection; pair p is seeded with
+ * seeds[p], or from base_seed and p when seeds == NULL (the reference seeds from
+ * std::random_device, i.e. is not reproducible: transform_estimate.cc:64-65).
+ * The result mirrors MatchInfo (stitch/match_info.hh:14-51): ok = get_transform()'s return,
+ * confidence (negative = -#inliers, as the reference leaves it on rejection), homo (image j ->
+ * image i), inlier indices into the pair's match list.
+ * ===================================================================================== */
+typedef struct op_ransac_result op_ransac_result;
+int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, const op_matches* m,
+		const int* pairs, int npairs, const int* shapes_wh, const uint32_t* seeds, uint32_t base_seed,
+		op_ransac_result** out);
+int op_ransac_ok(const op_ransac_result* r, int p);
+float op_ransac_confidence(const op_ransac_result* r, int p);
+int op_ransac_homo(const op_ransac_result* r, int p, double* h9);
+int op_ransac_inlier_count(const op_ransac_result* r, int p);
+int op_ransac_inliers(const op_ransac_result* r, int p, int* match_indices);
+/* index of the winning hypothesis and its inlier count (-1: no healthy hypothesis) */
+int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count);
+void op_ransac_free(op_ransac_result* r);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,8 @@ struct op_matches {
 	int64_t total = 0;
 };
 
+const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p) { return m->pairs[p]; }
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -319,6 +321,19 @@ done:
 	if (d_res) hipFree(d_res); if (d_work) hipFree(d_work); if (d_pds) hipFree(d_pds); if (d_blocks) hipFree(d_blocks);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
+	*out = m;
+	return OP_OK;
+}
+
+int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out) {
+	if (!idx_pairs || !counts || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_matches_from_host: bad argument");
+	op_matches* m = new op_matches;
+	m->npairs = npairs; m->pairs.resize(npairs);
+	for (int p = 0; p < npairs; ++p) {
+		if (counts[p] < 0) { delete m; OP_FAIL(OP_ERR_INVALID, "negative count"); }
+		m->pairs[p].assign(idx_pairs[p], idx_pairs[p] + 2 * (size_t)counts[p]);
+		m->total += counts[p];
+	}
 	*out = m;
 	return OP_OK;
 }

@@ -1,0 +1,403 @@
+// ransac.hip -- batched RANSAC homography / affine estimation for all matched image pairs.
+//
+// Replaces TransformEstimation::get_transform (stitch/transform_estimate.cc:49-87) as called per
+// pair by Stitcher::match_image (stitch/stitcher.cc:66-94) and CylinderStitcher
+// (stitch/cylstitcher.cc:75-77,115-117):
+//   device  one lane per hypothesis: 8-point (7 for affine) sample -> scale-normalised DLT ->
+//           health() -> inlier count over the pair's matches (staged in LDS); a second tiny
+//           kernel picks the first hypothesis with the maximal count (update_max semantics);
+//   host    the per-pair epilogue the reference runs once: inliers of the winner, refit on all
+//           inliers and the geometric acceptance gates of fill_inliers_to_matchinfo (:150-218),
+//           OpenMP-parallel over pairs.  It shares ransac_math.hpp with the kernel, so the
+//           winner's homography is recomputed bit-identically.
+// Sampling: the reference seeds std::mt19937 from std::random_device per call (unseeded,
+// SURVEY F4).  Here every pair gets an explicit 32-bit seed (caller-supplied or derived from a
+// base seed and the pair index); the draw sequence is std::mt19937's, with the reference's
+// rejection of repeated indices (:70-77), so a run is reproducible and can be replayed against
+// the CPU path with the same seed.
+#include "internal.hpp"
+#include "ransac_math.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <omp.h>
+
+struct op_features;
+struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
+FeatView op_features_view(const op_features* f);
+const double* op_features_coor_device(const op_features* f);
+struct op_matches;
+const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p);
+
+using opransac::P2;
+
+struct op_ransac_result {
+	struct Item {
+		int ok = 0; float confidence = 0; double homo[9] = {0};
+		std::vector<int> inliers;         // indices into the pair's match list
+		int best_count = -1, best_hyp = -1;
+	};
+	std::vector<Item> items;
+};
+
+namespace {
+
+struct PairArgs { int pts_off, m, affine, nsample; double inlier_dist; long long samp_off; };
+
+constexpr int RANSAC_PTS_CHUNK = 512;
+
+// grid (ceil(iters/256), npairs)
+__global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__ pairs, const double* __restrict__ pts /* m x {p1x,p1y,p2x,p2y} */,
+		const unsigned short* __restrict__ samples, int iters, int* __restrict__ counts /* npairs x iters */) {
+	__shared__ double s_pts[RANSAC_PTS_CHUNK * 4];
+	const PairArgs pa = pairs[blockIdx.y];
+	const int hyp = blockIdx.x * 256 + threadIdx.x;
+	const double* P = pts + (long long)pa.pts_off * 4;
+	double H[9];
+	bool ok = false;
+	if (hyp < iters && pa.m >= pa.nsample) {
+		const unsigned short* s = samples + pa.samp_off + (long long)hyp * 8;
+		int idx[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) idx[i] = s[i];
+		auto get1 = [&](int i) { const double* q = P + (long long)idx[i] * 4; return P2{q[0], q[1]}; };
+		auto get2 = [&](int i) { const double* q = P + (long long)idx[i] * 4; return P2{q[2], q[3]}; };
+		opransac::calc_transform(pa.nsample, get1, get2, pa.affine != 0, H);
+		ok = opransac::health(H);
+	}
+	int cnt = 0;
+	for (int cb = 0; cb < pa.m; cb += RANSAC_PTS_CHUNK) {
+		const int cn = pa.m - cb < RANSAC_PTS_CHUNK ? pa.m - cb : RANSAC_PTS_CHUNK;
+		__syncthreads();
+		for (int e = threadIdx.x; e < cn * 4; e += 256) s_pts[e] = P[(long long)cb * 4 + e];
+		__syncthreads();
+		if (ok)
+			for (int i = 0; i < cn; ++i)
+				cnt += opransac::is_inlier(H, P2{s_pts[4 * i], s_pts[4 * i + 1]}, P2{s_pts[4 * i + 2], s_pts[4 * i + 3]}, pa.inlier_dist) ? 1 : 0;
+	}
+	if (hyp < iters) counts[(long long)blockIdx.y * iters + hyp] = ok ? cnt : -1;
+}
+
+// first hypothesis with the maximal inlier count (update_max, transform_estimate.cc:82)
+__global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ counts, int iters, int2* __restrict__ best) {
+	__shared__ int s_cnt[256], s_idx[256];
+	const int* c = counts + (long long)blockIdx.x * iters;
+	int bc = -1, bi = -1;
+	for (int i = threadIdx.x; i < iters; i += 256) { const int v = c[i]; if (v > bc) { bc = v; bi = i; } }
+	s_cnt[threadIdx.x] = bc; s_idx[threadIdx.x] = bi;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (threadIdx.x < st) {
+			const int oc = s_cnt[threadIdx.x + st], oi = s_idx[threadIdx.x + st];
+			if (oc > s_cnt[threadIdx.x] || (oc == s_cnt[threadIdx.x] && oc >= 0 && oi < s_idx[threadIdx.x])) { s_cnt[threadIdx.x] = oc; s_idx[threadIdx.x] = oi; }
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) best[blockIdx.x] = make_int2(s_idx[0], s_cnt[0]);
+}
+
+// ---------------- host epilogue: fill_inliers_to_matchinfo and its helpers ----------------
+struct Shape { int w, h; };
+inline bool shifted_in(const Shape& s, P2 p) {        // match_info.hh:68-70
+	return p.x >= -s.w * 0.5 && p.x < s.w * 0.5 && p.y >= -s.h * 0.5 && p.y < s.h * 0.5;
+}
+inline double side(P2 a, P2 b, P2 p) { return (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x); }   // polygon.cc:9-11
+
+std::vector<P2> convex_hull(std::vector<P2>& pts) {  // lib/polygon.cc:17-46
+	if (pts.size() <= 3) return pts;
+	std::sort(pts.begin(), pts.end(), [](const P2& a, const P2& b) { if (a.y == b.y) return a.x < b.x; return a.y < b.y; });
+	std::vector<P2> ret;
+	ret.push_back(pts[0]); ret.push_back(pts[1]);
+	const int n = (int)pts.size();
+	for (int i = 2; i < n; ++i) {
+		while (ret.size() >= 2 && side(ret[ret.size() - 2], ret.back(), pts[i]) <= 0) ret.pop_back();
+		ret.push_back(pts[i]);
+	}
+	const size_t mid = ret.size();
+	ret.push_back(pts[n - 2]);
+	for (int i = n - 3; i >= 0; --i) {
+		while (ret.size() > mid && side(ret[ret.size() - 2], ret.back(), pts[i]) <= 0) ret.pop_back();
+		ret.push_back(pts[i]);
+	}
+	return ret;
+}
+
+double polygon_area(const std::vector<P2>& poly) {   // lib/polygon.cc:48-60
+	const int n = (int)poly.size();
+	double sum = 0;
+	for (int i = 0; i < n; ++i) sum += poly[i].x * (poly[(i + 1) % n].y - poly[(i + n - 1) % n].y);
+	return 0.5 * std::fabs(sum);
+}
+
+struct PointInPolygon {                               // lib/polygon.hh:30-52, polygon.cc:62-82
+	const std::vector<P2>& poly; P2 com; std::vector<std::pair<float, int>> slopes;
+	explicit PointInPolygon(const std::vector<P2>& p): poly(p) {
+		com = P2{0, 0};
+		for (auto& c : poly) { com.x += c.x; com.y += c.y; }
+		const double f = 1.0 / poly.size();
+		com.x *= f; com.y *= f;
+		for (size_t i = 0; i < p.size(); ++i) slopes.emplace_back((float)std::atan2(p[i].y - com.y, p[i].x - com.x), (int)i);
+		std::sort(slopes.begin(), slopes.end());
+	}
+	bool in_polygon(P2 p) const {
+		const float k = (float)std::atan2(p.y - com.y, p.x - com.x);
+		auto itr = std::lower_bound(slopes.begin(), slopes.end(), std::make_pair(k, 0));
+		int idx1, idx2;
+		if (itr == slopes.end()) { idx1 = slopes.back().second; idx2 = slopes.front().second; }
+		else { idx2 = itr->second; idx1 = (itr != slopes.begin()) ? (--itr)->second : slopes.back().second; }
+		const P2 p1 = poly[idx1], p2 = poly[idx2];
+		const double o1 = side(p1, p2, com), o2 = side(p1, p2, p);
+		return !(o1 * o2 < -1e-6);
+	}
+};
+
+inline P2 trans2d(const double (&H)[9], P2 m) {       // homography.hh:53-76
+	const double x = H[0] * m.x + H[1] * m.y + H[2] * 1.0, y = H[3] * m.x + H[4] * m.y + H[5] * 1.0, z = H[6] * m.x + H[7] * m.y + H[8] * 1.0;
+	const double d = 1.0 / z;
+	return P2{x * d, y * d};
+}
+
+// 3x3 inverse with complete pivoting (Homography::inverse, stitch/homography.cc:25-39)
+bool inverse3(const double (&a)[9], double (&inv)[9]) {
+	double lu[9]; std::memcpy(lu, a, sizeof(lu));
+	int rowt[3], colt[3], nonzero = 3; double maxpivot = 0;
+	for (int k = 0; k < 3; ++k) {
+		int br = k, bc = k; double best = -1;
+		for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j) { double v = std::fabs(lu[i * 3 + j]); if (v > best) { best = v; br = i; bc = j; } }
+		if (best == 0.0) { nonzero = k; for (int i = k; i < 3; ++i) rowt[i] = colt[i] = i; break; }
+		if (best > maxpivot) maxpivot = best;
+		rowt[k] = br; colt[k] = bc;
+		if (br != k) for (int j = 0; j < 3; ++j) std::swap(lu[k * 3 + j], lu[br * 3 + j]);
+		if (bc != k) for (int i = 0; i < 3; ++i) std::swap(lu[i * 3 + k], lu[i * 3 + bc]);
+		for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
+		for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j) lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
+	}
+	const double thr = std::fabs(maxpivot) * (2.220446049250313e-16 * 3);
+	int rank = 0;
+	for (int i = 0; i < nonzero; ++i) rank += (std::fabs(lu[i * 3 + i]) > thr);
+	if (rank != 3) return false;
+	for (int col = 0; col < 3; ++col) {
+		double c[3];
+		for (int i = 0; i < 3; ++i) c[i] = (i == col) ? 1.0 : 0.0;
+		for (int i = 0; i < 3; ++i) std::swap(c[i], c[rowt[i]]);
+		for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
+		for (int i = 2; i >= 0; --i) { for (int j = i + 1; j < 3; ++j) c[i] -= lu[i * 3 + j] * c[j]; c[i] /= lu[i * 3 + i]; }
+		for (int i = 2; i >= 0; --i) std::swap(c[i], c[colt[i]]);
+		for (int i = 0; i < 3; ++i) inv[i * 3 + col] = c[i];
+	}
+	return true;
+}
+
+// overlap_region (stitch/homography.cc:50-90): homo maps shape2 -> shape1, inv the reverse
+std::vector<P2> overlap_region(const Shape& shape1, const Shape& shape2, const double (&homo)[9], const double (&inv)[9]) {
+	const int NR = 100;
+	const float stepw = (float)(shape2.w * 1.0 / NR), steph = (float)(shape2.h * 1.0 / NR);
+	const double hw = shape2.w * 0.5, hh = shape2.h * 0.5;
+	std::vector<P2> pts2in1;
+	for (int i = 0; i < NR; ++i) {
+		const P2 e[4] = { P2{-hw + i * stepw, -hh}, P2{-hw + i * stepw, hh}, P2{-hw, -hh + i * steph}, P2{hw, -hh + i * steph} };
+		for (int k = 0; k < 4; ++k) {
+			// Matrix product 3x3 * 3x(4 NR) then float denom = 1.0 / z (:72-76)
+			const double x = homo[0] * e[k].x + homo[1] * e[k].y + homo[2] * 1.0;
+			const double y = homo[3] * e[k].x + homo[4] * e[k].y + homo[5] * 1.0;
+			const double z = homo[6] * e[k].x + homo[7] * e[k].y + homo[8] * 1.0;
+			const float denom = (float)(1.0 / z);
+			const P2 pin1{x * denom, y * denom};
+			if (shifted_in(shape1, pin1)) pts2in1.push_back(pin1);
+		}
+	}
+	const P2 corners[4] = { P2{-shape1.w * 0.5, -shape1.h * 0.5}, P2{shape1.w * 0.5, -shape1.h * 0.5}, P2{-shape1.w * 0.5, shape1.h * 0.5}, P2{shape1.w * 0.5, shape1.h * 0.5} };
+	for (auto& c : corners) if (shifted_in(shape2, trans2d(inv, c))) pts2in1.push_back(c);
+	return convex_hull(pts2in1);
+}
+
+struct PairHost {
+	int i, j, m;
+	const int* match;              // m x (first, second)
+	const double* kp1; int nk1;    // image i keypoints (x, y) centred
+	const double* kp2; int nk2;
+	Shape s1, s2;
+	std::vector<double> pts;       // m x 4
+};
+
+}	// namespace
+
+extern "C" {
+
+int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, const op_matches* mt,
+		const int* pairs, int npairs, const int* shapes_wh, const uint32_t* seeds, uint32_t base_seed,
+		op_ransac_result** out) {
+	if (!ctx || !cfg || !f || !mt || !pairs || npairs < 0 || !shapes_wh || !out) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const FeatView fv = op_features_view(f);
+	const long long total = fv.offsets[fv.n];
+	op_ransac_result* R = new op_ransac_result;
+	R->items.resize(npairs);
+	if (npairs == 0) { *out = R; return OP_OK; }
+	const bool affine = cfg->CYLINDER || cfg->TRANS;                    // transform_estimate.cc:34-37
+	const int nsample = (affine ? 6 : 8) / 2 + 4;                       // :53
+	const int iters = cfg->RANSAC_ITERATIONS;
+	if (iters <= 0 || iters > 65536) { delete R; OP_FAIL(OP_ERR_UNSUPPORTED, "RANSAC_ITERATIONS must be in [1, 65536]"); }
+
+	std::vector<double> coor((size_t)std::max<long long>(total, 1) * 2);
+	if (total) HIPCHK(hipMemcpyAsync(coor.data(), op_features_coor_device(f), sizeof(double) * 2 * total, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+
+	std::vector<PairHost> ph(npairs);
+	std::vector<PairArgs> pa(npairs);
+	long long pts_total = 0;
+	for (int p = 0; p < npairs; ++p) {
+		const int i = pairs[2 * p], j = pairs[2 * p + 1];
+		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) { delete R; OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: image index out of range"); }
+		const std::vector<int>& mv = op_matches_pair_vector(mt, p);
+		PairHost& h = ph[p];
+		h.i = i; h.j = j; h.m = (int)(mv.size() / 2); h.match = mv.data();
+		h.kp1 = coor.data() + fv.offsets[i] * 2; h.nk1 = fv.counts[i];
+		h.kp2 = coor.data() + fv.offsets[j] * 2; h.nk2 = fv.counts[j];
+		h.s1 = Shape{shapes_wh[2 * i], shapes_wh[2 * i + 1]}; h.s2 = Shape{shapes_wh[2 * j], shapes_wh[2 * j + 1]};
+		if (h.m > 65535) { delete R; OP_FAIL(OP_ERR_CAPACITY, "more than 65535 matches in one pair"); }
+		h.pts.resize((size_t)h.m * 4);
+		for (int k = 0; k < h.m; ++k) {
+			const int a = h.match[2 * k], b = h.match[2 * k + 1];
+			h.pts[4 * k] = h.kp1[2 * a]; h.pts[4 * k + 1] = h.kp1[2 * a + 1];
+			h.pts[4 * k + 2] = h.kp2[2 * b]; h.pts[4 * k + 3] = h.kp2[2 * b + 1];
+		}
+		// ransac_inlier_thres (float) and INLIER_DIST = sqr(float) (transform_estimate.cc:46,133)
+		const float thres = (float)((h.s1.w + h.s1.h) * 0.5 / 800 * cfg->RANSAC_INLIER_THRES);
+		const float inlier_dist = thres * thres;
+		pa[p] = PairArgs{(int)pts_total, h.m, affine ? 1 : 0, nsample, (double)inlier_dist, (long long)p * iters * 8};
+		pts_total += h.m;
+	}
+	// sample tables: std::mt19937 draw sequence with rejection of repeats (:67-77)
+	std::vector<unsigned short> samples((size_t)npairs * iters * 8, 0);
+#pragma omp parallel for schedule(dynamic)
+	for (int p = 0; p < npairs; ++p) {
+		const int m = ph[p].m;
+		if (m < 8 || m < nsample) continue;             // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
+		opransac::MT19937 rng;
+		rng.seed(seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u));
+		unsigned short* sp = samples.data() + (size_t)p * iters * 8;
+		for (int K = 0; K < iters; ++K) {
+			int sel[8];
+			for (int t = 0; t < nsample; ++t) {
+				int r; bool dup;
+				do {
+					r = (int)(rng.next() % (unsigned)m);
+					dup = false;
+					for (int q = 0; q < t; ++q) dup |= (sel[q] == r);
+				} while (dup);
+				sel[t] = r; sp[K * 8 + t] = (unsigned short)r;
+			}
+		}
+	}
+	std::vector<double> pts_flat((size_t)std::max<long long>(pts_total, 1) * 4);
+	for (int p = 0; p < npairs; ++p) if (ph[p].m) std::memcpy(pts_flat.data() + (size_t)pa[p].pts_off * 4, ph[p].pts.data(), sizeof(double) * 4 * ph[p].m);
+
+	PairArgs* d_pa = nullptr; double* d_pts = nullptr; unsigned short* d_samp = nullptr; int* d_counts = nullptr; int2* d_best = nullptr;
+	std::vector<int2> best(npairs);
+	int rc = OP_OK;
+#define RCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
+	RCHK(hipMalloc(&d_pa, sizeof(PairArgs) * npairs));
+	RCHK(hipMalloc(&d_pts, sizeof(double) * pts_flat.size()));
+	RCHK(hipMalloc(&d_samp, sizeof(unsigned short) * samples.size()));
+	RCHK(hipMalloc(&d_counts, sizeof(int) * (size_t)npairs * iters));
+	RCHK(hipMalloc(&d_best, sizeof(int2) * npairs));
+	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
+	RCHK(hipMemcpyAsync(d_pts, pts_flat.data(), sizeof(double) * pts_flat.size(), hipMemcpyHostToDevice, st));
+	RCHK(hipMemcpyAsync(d_samp, samples.data(), sizeof(unsigned short) * samples.size(), hipMemcpyHostToDevice, st));
+	{
+		ProfScope ps(ctx, "get_transform");
+		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, npairs), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts);
+		RCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_ransac_best, dim3(npairs), dim3(256), 0, st, d_counts, iters, d_best);
+		RCHK(hipGetLastError());
+	}
+	RCHK(hipMemcpyAsync(best.data(), d_best, sizeof(int2) * npairs, hipMemcpyDeviceToHost, st));
+	RCHK(hipStreamSynchronize(st));
+	resolve_profile(ctx);
+
+	// ---- host epilogue per pair (transform_estimate.cc:85-86, 150-218) ----
+#pragma omp parallel for schedule(dynamic)
+	for (int p = 0; p < npairs; ++p) {
+		op_ransac_result::Item& it = R->items[p];
+		const PairHost& h = ph[p];
+		it.best_hyp = best[p].x; it.best_count = best[p].y;
+		if (h.m < 8 || h.m < nsample || best[p].x < 0 || best[p].y < 0) continue;     // get_transform -> false
+		const unsigned short* sp = samples.data() + (size_t)p * iters * 8 + (size_t)best[p].x * 8;
+		const double* P = h.pts.data();
+		double Hb[9];
+		opransac::calc_transform(nsample, [&](int q) { return P2{P[4 * sp[q]], P[4 * sp[q] + 1]}; },
+				[&](int q) { return P2{P[4 * sp[q] + 2], P[4 * sp[q] + 3]}; }, affine, Hb);
+		const double inlier_dist = pa[p].inlier_dist;
+		std::vector<int> inl;
+		for (int k = 0; k < h.m; ++k)
+			if (opransac::is_inlier(Hb, P2{P[4 * k], P[4 * k + 1]}, P2{P[4 * k + 2], P[4 * k + 3]}, inlier_dist)) inl.push_back(k);
+		it.confidence = -(float)inl.size();                                           // :153
+		it.inliers = inl;
+		if (inl.size() < 8) continue;                                                 // :154
+		double homo[9], inv[9];
+		opransac::calc_transform((int)inl.size(), [&](int q) { return P2{P[4 * inl[q]], P[4 * inl[q] + 1]}; },
+				[&](int q) { return P2{P[4 * inl[q] + 2], P[4 * inl[q] + 3]}; }, affine, homo);   // :179
+		if (!inverse3(homo, inv)) continue;                                           // :182-184
+		auto match_cnt = [&](const std::vector<P2>& poly, bool first) {
+			if (poly.size() < 3) return 0;
+			PointInPolygon pip(poly);
+			int c = 0;
+			for (int k = 0; k < h.m; ++k) c += pip.in_polygon(first ? P2{P[4 * k], P[4 * k + 1]} : P2{P[4 * k + 2], P[4 * k + 3]}) ? 1 : 0;
+			return c;
+		};
+		auto keypoint_cnt = [&](const std::vector<P2>& poly, bool first, bool& valid) {
+			valid = poly.size() >= 3;          // the reference asserts here (polygon.hh:32)
+			if (!valid) return 0;
+			PointInPolygon pip(poly);
+			const double* kp = first ? h.kp1 : h.kp2; const int nk = first ? h.nk1 : h.nk2;
+			int c = 0;
+			for (int k = 0; k < nk; ++k) c += pip.in_polygon(P2{kp[2 * k], kp[2 * k + 1]}) ? 1 : 0;
+			return c;
+		};
+		bool valid = true;
+		std::vector<P2> overlap = overlap_region(h.s1, h.s2, homo, inv);
+		const float r1m = inl.size() * 1.0f / match_cnt(overlap, true);
+		if (r1m < cfg->INLIER_IN_MATCH_RATIO) continue;
+		const float r1p = inl.size() * 1.0f / keypoint_cnt(overlap, true, valid);
+		if (!valid || r1p < 0.01 || r1p > 1) continue;
+		overlap = overlap_region(h.s2, h.s1, inv, homo);
+		const float r2m = inl.size() * 1.0f / match_cnt(overlap, false);
+		if (r2m < cfg->INLIER_IN_MATCH_RATIO) continue;
+		const float r2p = inl.size() * 1.0f / keypoint_cnt(overlap, false, valid);
+		if (!valid || r2p < 0.01 || r2p > 1) continue;
+		it.confidence = (float)((r1p + r2p) * 0.5);                                   // :200
+		if (it.confidence < cfg->INLIER_IN_POINTS_RATIO) continue;
+		const double area = polygon_area(overlap);
+		const double area1 = (double)(h.s1.w * h.s1.h), area2 = (double)(h.s2.w * h.s2.h);
+		if (area / std::max(area1, area2) < 0.15) continue;
+		std::memcpy(it.homo, homo, sizeof(homo));
+		it.ok = 1;
+	}
+done:
+	if (d_pa) hipFree(d_pa); if (d_pts) hipFree(d_pts); if (d_samp) hipFree(d_samp); if (d_counts) hipFree(d_counts); if (d_best) hipFree(d_best);
+#undef RCHK
+	if (rc != OP_OK) { delete R; return rc; }
+	*out = R;
+	return OP_OK;
+}
+
+int op_ransac_ok(const op_ransac_result* r, int p) { return (r && p >= 0 && p < (int)r->items.size()) ? r->items[p].ok : 0; }
+float op_ransac_confidence(const op_ransac_result* r, int p) { return (r && p >= 0 && p < (int)r->items.size()) ? r->items[p].confidence : 0.f; }
+int op_ransac_homo(const op_ransac_result* r, int p, double* h9) {
+	if (!r || p < 0 || p >= (int)r->items.size() || !h9) OP_FAIL(OP_ERR_INVALID, "op_ransac_homo: bad argument");
+	std::memcpy(h9, r->items[p].homo, sizeof(double) * 9); return OP_OK;
+}
+int op_ransac_inlier_count(const op_ransac_result* r, int p) { return (r && p >= 0 && p < (int)r->items.size()) ? (int)r->items[p].inliers.size() : 0; }
+int op_ransac_inliers(const op_ransac_result* r, int p, int* match_indices) {
+	if (!r || p < 0 || p >= (int)r->items.size() || !match_indices) OP_FAIL(OP_ERR_INVALID, "op_ransac_inliers: bad argument");
+	std::copy(r->items[p].inliers.begin(), r->items[p].inliers.end(), match_indices); return OP_OK;
+}
+int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count) {
+	if (!r || p < 0 || p >= (int)r->items.size()) OP_FAIL(OP_ERR_INVALID, "op_ransac_best: bad argument");
+	if (hyp) *hyp = r->items[p].best_hyp; if (count) *count = r->items[p].best_count; return OP_OK;
+}
+void op_ransac_free(op_ransac_result* r) { delete r; }
+
+}	// extern "C"

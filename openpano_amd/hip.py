@@ -130,6 +130,17 @@ def lib():
         L.op_matches_total.restype = C.c_int64
         L.op_matches_total.argtypes = [C.c_void_p]
         L.op_matches_free.argtypes = [C.c_void_p]
+    L.op_matches_from_host.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_ransac_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.op_ransac_ok.argtypes = [C.c_void_p, C.c_int]
+    L.op_ransac_confidence.restype = C.c_float
+    L.op_ransac_confidence.argtypes = [C.c_void_p, C.c_int]
+    L.op_ransac_homo.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.op_ransac_inlier_count.argtypes = [C.c_void_p, C.c_int]
+    L.op_ransac_inliers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.op_ransac_best.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_ransac_free.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -344,6 +355,81 @@ def debug_math(ctx: Context, which: int, x, y=None):
     y = np.ascontiguousarray(y, np.float32) if y is not None else x
     out = np.empty_like(x)
     check(lib().op_debug_math(ctx.handle, which, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+class Matches:
+    """``op_matches`` handle (kept for the RANSAC stage)."""
+
+    def __init__(self, handle, npairs):
+        self.handle = handle; self.npairs = npairs
+
+    def lists(self):
+        L = lib(); out = []
+        for p in range(self.npairs):
+            n = L.op_matches_count(self.handle, p)
+            a = np.empty((n, 2), np.int32)
+            if n:
+                check(L.op_matches_copy(self.handle, p, a.ctypes.data_as(C.c_void_p)))
+            out.append(a)
+        return out
+
+    @classmethod
+    def from_host(cls, lists):
+        lists = [np.ascontiguousarray(a, np.int32).reshape(-1, 2) for a in lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p) for a in lists])
+        counts = (C.c_int * n)(*[len(a) for a in lists])
+        h = C.c_void_p()
+        check(lib().op_matches_from_host(ptrs, counts, n, C.byref(h)))
+        return cls(h, n)
+
+    def free(self):
+        if self.handle:
+            lib().op_matches_free(self.handle); self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def match_pairs_handle(ctx: Context, cfg, feats: Features, pairs) -> Matches:
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(lib().op_match_pairs(ctx.handle, C.byref(ccfg), feats.handle, pr.ctypes.data_as(C.c_void_p), len(pr), C.byref(h)))
+    return Matches(h, len(pr))
+
+
+def ransac_pairs(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, seeds=None, base_seed=0):
+    """Batched TransformEstimation::get_transform. shapes_wh: (n_images, 2) of (w, h).
+    -> list of dict(ok, confidence, homo (3,3), inliers, best_hyp, best_count) per pair."""
+    L = lib()
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+    sd = np.ascontiguousarray(np.asarray(seeds, np.uint32)) if seeds is not None else None
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
+                            sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
+                            int(base_seed), C.byref(h)))
+    out = []
+    try:
+        for p in range(len(pr)):
+            homo = np.zeros(9, np.float64)
+            check(L.op_ransac_homo(h, p, homo.ctypes.data_as(C.c_void_p)))
+            n = L.op_ransac_inlier_count(h, p)
+            inl = np.empty(n, np.int32)
+            if n:
+                check(L.op_ransac_inliers(h, p, inl.ctypes.data_as(C.c_void_p)))
+            bh = C.c_int(); bc = C.c_int()
+            check(L.op_ransac_best(h, p, C.byref(bh), C.byref(bc)))
+            out.append(dict(ok=bool(L.op_ransac_ok(h, p)), confidence=L.op_ransac_confidence(h, p), homo=homo.reshape(3, 3),
+                            inliers=inl, best_hyp=bh.value, best_count=bc.value))
+    finally:
+        L.op_ransac_free(h)
     return out
 
 

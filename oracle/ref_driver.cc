@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include <omp.h>
+#include <random>
 
 #include "lib/config.hh"
 #include "lib/mat.h"
@@ -26,9 +27,18 @@
 #include "feature/sift.hh"
 #include "feature/matcher.hh"
 #include "feature/gaussian.hh"
+#include "stitch/transform_estimate.hh"
+#include "stitch/match_info.hh"
 
 using namespace pano;
 using namespace config;
+
+// RNG injection seam: TransformEstimation::get_transform seeds std::mt19937 from
+// std::random_device (transform_estimate.cc:64-65).  The reference TU calls the out-of-line
+// libstdc++ member _M_getval(); this definition (bound inside this .so by -Wl,-Bsymbolic)
+// returns the seed chosen by the test instead of entropy.
+static unsigned g_ref_seed = 0;
+namespace std { unsigned int random_device::_M_getval() { return g_ref_seed; } }
 
 namespace {
 
@@ -224,6 +234,33 @@ int ref_match_flann(const float* d1, int n1, const float* d2, int n2, int* out) 
 	std::sort(md.data.begin(), md.data.end());
 	for (size_t i = 0; i < md.data.size(); ++i) { out[2 * i] = md.data[i].first; out[2 * i + 1] = md.data[i].second; }
 	return md.size();
+}
+
+// TransformEstimation(...).get_transform(&info) (stitch/transform_estimate.cc:26-87) with an injected
+// seed. inlier_pts receives info.match as (to.x, to.y, from.x, from.y) rows. Returns the bool.
+int ref_ransac(const int* match, int m, const double* kp1, int nk1, const double* kp2, int nk2,
+		int w1, int h1, int w2, int h2, unsigned seed,
+		float* confidence, double* homo, double* inlier_pts, int* n_inliers) {
+	MatchData md;
+	for (int i = 0; i < m; ++i) md.data.emplace_back(match[2 * i], match[2 * i + 1]);
+	std::vector<Vec2D> k1, k2;
+	for (int i = 0; i < nk1; ++i) k1.emplace_back(kp1[2 * i], kp1[2 * i + 1]);
+	for (int i = 0; i < nk2; ++i) k2.emplace_back(kp2[2 * i], kp2[2 * i + 1]);
+	g_ref_seed = seed;
+	MatchInfo info;
+	TransformEstimation te(md, k1, k2, Shape2D(w1, h1), Shape2D(w2, h2));
+	bool ok = te.get_transform(&info);
+	*confidence = info.confidence;
+	*n_inliers = 0;
+	if (ok) {
+		for (int i = 0; i < 9; ++i) homo[i] = info.homo[i];
+		*n_inliers = (int)info.match.size();
+		for (size_t i = 0; i < info.match.size(); ++i) {
+			inlier_pts[4 * i] = info.match[i].first.x; inlier_pts[4 * i + 1] = info.match[i].first.y;
+			inlier_pts[4 * i + 2] = info.match[i].second.x; inlier_pts[4 * i + 3] = info.match[i].second.y;
+		}
+	}
+	return ok ? 1 : 0;
 }
 
 float ref_euclidean_sqr(const float* x, const float* y, int n, float thres) {

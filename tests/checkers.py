@@ -147,8 +147,30 @@ class Oracle(_StagedBase):
         lib.orc_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
         lib.orc_match_exact.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, _i32p]
 
+        lib.orc_ransac.argtypes = [_i32p, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_uint,
+                                   C.POINTER(C.c_float), _f64p, _i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
     def _cp(self):
         return C.byref(self.ccfg)
+
+    def ransac(self, match, kp1, kp2, shape1, shape2, seed, cfg=None):
+        """TransformEstimation(...).get_transform with an injected mt19937 seed.
+        shape = (w, h). -> dict(ok, confidence, homo, inliers (match indices), best_hyp, best_count)"""
+        cfg = cfg or self.cfg
+        match = np.ascontiguousarray(match, np.int32).reshape(-1, 2)
+        kp1 = np.ascontiguousarray(kp1, np.float64).reshape(-1, 2); kp2 = np.ascontiguousarray(kp2, np.float64).reshape(-1, 2)
+        conf = C.c_float(); homo = np.zeros(9, np.float64); inl = np.zeros(max(len(match), 1), np.int32)
+        ni = C.c_int(); bh = C.c_int(); bc = C.c_int()
+        affine = int(bool(cfg.CYLINDER) or bool(cfg.TRANS))
+        ok = self.lib.orc_ransac(match.reshape(-1) if len(match) else np.zeros(2, np.int32), len(match),
+                                 kp1.reshape(-1) if len(kp1) else np.zeros(2), len(kp1),
+                                 kp2.reshape(-1) if len(kp2) else np.zeros(2), len(kp2),
+                                 shape1[0], shape1[1], shape2[0], shape2[1], affine, cfg.RANSAC_ITERATIONS,
+                                 cfg.RANSAC_INLIER_THRES, cfg.INLIER_IN_MATCH_RATIO, cfg.INLIER_IN_POINTS_RATIO, int(seed),
+                                 C.byref(conf), homo, inl, C.byref(ni), C.byref(bh), C.byref(bc))
+        return dict(ok=bool(ok), confidence=conf.value, homo=homo.reshape(3, 3), inliers=inl[: ni.value].copy(),
+                    best_hyp=bh.value, best_count=bc.value)
 
     def sift_stages(self, img, planes=True):
         img = np.ascontiguousarray(img, np.float32)
@@ -222,6 +244,20 @@ class Ref(_StagedBase):
         lib.ref_euclidean_sqr.restype = C.c_float
         lib.ref_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
         lib.ref_gauss_kernel.argtypes = [C.c_float, _f32p]
+        lib.ref_ransac.argtypes = [_i32p, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
+                                   C.POINTER(C.c_float), _f64p, _f64p, C.POINTER(C.c_int)]
+
+    def set_config(self, **kv):
+        for k, v in kv.items():
+            assert self.lib.ref_config_set(k.encode(), float(np.float32(v))) == 0, k
+
+    def ransac(self, match, kp1, kp2, shape1, shape2, seed):
+        match = np.ascontiguousarray(match, np.int32).reshape(-1, 2)
+        kp1 = np.ascontiguousarray(kp1, np.float64).reshape(-1, 2); kp2 = np.ascontiguousarray(kp2, np.float64).reshape(-1, 2)
+        conf = C.c_float(); homo = np.zeros(9, np.float64); pts = np.zeros((max(len(match), 1), 4), np.float64); ni = C.c_int()
+        ok = self.lib.ref_ransac(match.reshape(-1), len(match), kp1.reshape(-1), len(kp1), kp2.reshape(-1), len(kp2),
+                                 shape1[0], shape1[1], shape2[0], shape2[1], int(seed), C.byref(conf), homo, pts.reshape(-1), C.byref(ni))
+        return dict(ok=bool(ok), confidence=conf.value, homo=homo.reshape(3, 3), inlier_pts=pts[: ni.value].copy())
 
     def sift_stages(self, img, planes=True):
         img = np.ascontiguousarray(img, np.float32)

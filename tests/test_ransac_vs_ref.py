@@ -1,0 +1,72 @@
+"""CPU, build container: the RANSAC oracle (oracle/ransac_oracle.c) against the reference's own
+TransformEstimation compiled in place (oracle/_ref) with the same injected mt19937 seed.
+
+The reference solves its DLT with Eigen::JacobiSVD (system Eigen, absent: the _ref build uses the
+mini stand-in), the oracle with a Givens QR -- so homographies agree to rounding, not bit for
+bit, and the inlier set may differ only for points within that rounding of the threshold."""
+import numpy as np
+import pytest
+
+from openpano_amd import synth
+
+
+def _scene(oracle, h, w, seed, shift):
+    world = synth.make_world(seed, h + 48, w + shift + 48, work_scale=1600.0 / (h + w))
+    a = synth.cut_view(world, 24, 24, h, w, seed * 10 + 1)
+    b = synth.cut_view(world, 24, 24 + shift, h, w, seed * 10 + 2)
+    da, ca = oracle.detect_feature(a)
+    db, cb = oracle.detect_feature(b)
+    m = oracle.match_exact(da, db)
+    return m, ca, cb
+
+
+def _same_inliers(m, ca, cb, ref_pts, orc_idx):
+    # the reference reports MatchInfo coordinate pairs (keypoints with several orientations share
+    # coordinates, so compare as multisets of coordinates, in order)
+    mine = [(ca[m[k][0]][0], ca[m[k][0]][1], cb[m[k][1]][0], cb[m[k][1]][1]) for k in orc_idx]
+    return mine == [tuple(p) for p in ref_pts]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 12345, 4000000000])
+def test_homography_ransac_matches_reference(oracle, ref, seed):
+    m, ca, cb = _scene(oracle, 400, 600, 21, 260)
+    assert len(m) > 40
+    o = oracle.ransac(m, ca, cb, (600, 400), (600, 400), seed)
+    r = ref.ransac(m, ca, cb, (600, 400), (600, 400), seed)
+    assert o["ok"] and r["ok"]
+    assert np.allclose(o["homo"], r["homo"], rtol=1e-7, atol=1e-9)
+    assert abs(o["confidence"] - r["confidence"]) < 1e-6
+    assert _same_inliers(m, ca, cb, r["inlier_pts"], o["inliers"])
+    # the two views are a 260 px horizontal shift of each other (small seeded rotations on top)
+    assert abs(o["homo"][0, 2] - 260) < 30 and abs(o["homo"][1, 2]) < 30
+
+
+def test_rejections_match_reference(oracle, ref):
+    # unrelated images: whatever the matcher returns must not survive the geometric gates
+    m1, ca, _ = _scene(oracle, 400, 600, 31, 200)
+    _, _, cb = _scene(oracle, 400, 600, 32, 200)
+    rng = np.random.default_rng(0)
+    fake = np.stack([rng.permutation(len(ca))[:60], rng.permutation(len(cb))[:60]], 1).astype(np.int32)
+    o = oracle.ransac(fake, ca, cb, (600, 400), (600, 400), 7)
+    r = ref.ransac(fake, ca, cb, (600, 400), (600, 400), 7)
+    assert o["ok"] == r["ok"] is False
+    assert o["confidence"] == r["confidence"]       # -(number of inliers) on rejection (:153)
+    # fewer than 8 matches: get_transform returns false without touching info (:55)
+    o = oracle.ransac(m1[:7], ca, ca, (600, 400), (600, 400), 3)
+    assert not o["ok"] and o["confidence"] == 0
+
+
+def test_affine_mode_matches_reference(oracle, ref, cfg):
+    from openpano_amd.config import PanoConfig
+    cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+    m, ca, cb = _scene(oracle, 400, 600, 41, 240)
+    ref.set_config(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+    try:
+        o = oracle.ransac(m, ca, cb, (600, 400), (600, 400), 99, cfg=cyl)
+        r = ref.ransac(m, ca, cb, (600, 400), (600, 400), 99)
+    finally:
+        ref.set_config(CYLINDER=0, ESTIMATE_CAMERA=1, ORDERED_INPUT=0)
+    assert o["ok"] and r["ok"]
+    assert np.allclose(o["homo"], r["homo"], rtol=1e-7, atol=1e-9)
+    assert o["homo"][2, 0] == 0 and o["homo"][2, 1] == 0 and o["homo"][2, 2] == 1   # affine
+    assert _same_inliers(m, ca, cb, r["inlier_pts"], o["inliers"])
