@@ -187,6 +187,52 @@ int op_ransac_inliers(const op_ransac_result* r, int p, int* match_indices);
 int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count);
 void op_ransac_free(op_ransac_result* r);
 
+/* =====================================================================================
+ * WARP + BLEND -- replaces ConnectedImages::blend() (stitch/stitcher_image.hh:92,
+ * stitch/stitcher_image.cc:116-155) together with the blender it constructs:
+ * LinearBlender (stitch/blender.cc:24-96; cfg->MULTIBAND == 0, both cfg->LAZY_READ branches,
+ * weights per cfg->ORDERED_INPUT) or MultiBandBlender(cfg->MULTIBAND) (stitch/multiband.cc:19-151).
+ * BlenderBase::add_image takes the coordinate map as a std::function (stitch/blender.hh:52-56),
+ * which a device cannot call, so the seam sits one level up and the map travels as PODs:
+ * projection method, proj_range.min, resolution and homo_inv per image.
+ * Pixels are the reference's to within 1e-4 (identical whenever the device's fp64 sin/cos/tan
+ * round like glibc's; colour arithmetic is the reference's fp32 sequence); Color::NO = -1 marks
+ * "no pixel" on input and output (lib/color.cc:11-15).
+ * ===================================================================================== */
+typedef struct op_blend_image {
+	const float* data;    /* H x W x 3 fp32 (ImageRef::img, stitch/imageref.hh:15-17) */
+	int h, w;
+	int on_device;
+	double homo_inv[9];   /* ImageComponent::homo_inv (stitch/stitcher_image.hh:40-42) */
+	double range[4];      /* ImageComponent::range: min.x, min.y, max.x, max.y (:48) */
+} op_blend_image;
+typedef struct op_blend_geom {
+	int proj_method;      /* ConnectedImages::ProjectionMethod (:30): 0 flat, 1 cylindrical, 2 spherical */
+	double proj_min[2], proj_max[2];   /* ConnectedImages::proj_range (:33) */
+	double resolution[2];              /* ConnectedImages::get_final_resolution() (stitcher_image.cc:79-114) */
+} op_blend_geom;
+/* HOST-side O(n) geometry the reference also runs on the host, in fp64 with the host libm:
+ * calc_inverse_homo + update_proj_range + get_final_resolution (stitcher_image.cc:36-114).
+ * homo: n x 9 ImageComponent::homo; shapes_wh: n x (w, h).  Fills g, homo_inv (n x 9) and
+ * ranges (n x 4).  OP_ERR_INVALID where the reference would m_assert / error_exit. */
+int op_blend_prepare(const op_config* cfg, int proj_method, int identity_idx, int n, const int* shapes_wh,
+		const double* homo, op_blend_geom* g, double* homo_inv, double* ranges);
+/* canvas size LinearBlender/MultiBandBlender::add_image arrive at (blender.cc:15-22) */
+int op_blend_canvas_dims(const op_blend_geom* g, const op_blend_image* imgs, int n, int* h, int* w);
+typedef struct op_canvas op_canvas;   /* device-resident H x W x 3 fp32 result (Mat32f) */
+int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op_blend_image* imgs, int n, op_canvas** out);
+int op_canvas_dims(const op_canvas* c, int* h, int* w);
+const float* op_canvas_device(const op_canvas* c);
+int op_canvas_copy(op_ctx* ctx, const op_canvas* c, float* host);
+void op_canvas_free(op_canvas* c);
+
+/* CYLINDER mode pre-warp -- replaces CylinderWarper::warp (stitch/warp.hh:47-55, warp.cc:13-75).
+ * op_cyl_warp_shape is the host part (projector, output shape, offset and the keypoints, which
+ * are centred coordinates updated in place: warp.cc:46-67); op_cyl_warp renders the pixels. */
+int op_cyl_warp_shape(const op_config* cfg, int w, int h, double h_factor, double* pts, int npts,
+		int* new_w, int* new_h, double* offset);
+int op_cyl_warp(op_ctx* ctx, const op_config* cfg, const op_image* img, double h_factor, op_canvas** out);
+
 #ifdef __cplusplus
 }
 #endif

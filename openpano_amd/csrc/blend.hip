@@ -1,0 +1,594 @@
+// blend.hip -- final warp + blend on the device.
+//
+// Replaces, for the whole bundle per launch:
+//   ConnectedImages::blend            stitch/stitcher_image.cc:116-155 (inverse map per canvas pixel,
+//                                     stitch/projection.hh:14-71, Homography::trans homography.hh:53-58)
+//   LinearBlender::run                stitch/blender.cc:24-96 (both LAZY_READ branches)
+//   MultiBandBlender::run             stitch/multiband.cc:19-151 (+ GaussianBlur::blur<WeightedPixel>,
+//                                     feature/gaussian.hh:30-91)
+//   interpolate                       lib/imgproc.cc:135-156
+//   CylinderProject::project          stitch/warp.cc:25-44
+// and keeps on the host, in fp64 with the host libm exactly like the reference, the O(n)
+// geometry: calc_inverse_homo / update_proj_range / get_final_resolution
+// (stitcher_image.cc:36-114) and the bounds of CylinderProject::project(Shape2D&) (warp.cc:46-67).
+//
+// The blender API of the reference takes the coordinate map as an opaque std::function
+// (blender.hh:52-56), which a device cannot call; the seam is therefore one level up, at
+// ConnectedImages::blend, and the map is passed as PODs (projection method, proj_range.min,
+// resolution, homo_inv per image).
+//
+// Numerics: coordinates in fp64 exactly in the reference's operation order (this TU is built
+// with -ffp-contract=off); sin/cos/tan are the device's fp64 libm, which can differ from glibc
+// in the last ulp -- after the reference's own narrowing of coordinates to float that is
+// invisible except on measure-zero boundaries, hence the 1e-4 pixel tolerance north_star states
+// (tests assert it, and report the exact-equal fraction).  Colour arithmetic is fp32 in the
+// reference's order, so equal coordinates give bit-equal pixels.
+#include "internal.hpp"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+struct op_canvas {
+	float* data = nullptr;   // device, h x w x 3
+	int h = 0, w = 0;
+	int device = 0;
+};
+
+namespace {
+
+struct BlendImg {
+	const float* data; int h, w;
+	int x0, y0, x1, y1;        // ROI on the canvas, inclusive (BlenderBase::Range, blender.hh:19-27)
+	double hinv[9];
+	long long roi_off;         // multiband: offset (pixels) of this image's ROI planes
+	int rw, rh;
+};
+
+struct BlendGeom { int method; double minx, miny, resx, resy; };
+
+// stitch/projection.hh:29-31,38-40,66-68
+__device__ __forceinline__ void proj2homo(int method, double x, double y, double& hx, double& hy, double& hz) {
+	if (method == 0) { hx = x; hy = y; hz = 1.0; }
+	else if (method == 1) { hx = sin(x); hy = y; hz = cos(x); }
+	else { hx = sin(x); hy = tan(y); hz = cos(x); }
+}
+
+// the lambda of ConnectedImages::blend (stitcher_image.cc:143-151) after proj2homo
+__device__ __forceinline__ void space_to_image(const BlendImg& im, double hx, double hy, double hz, double& ox, double& oy) {
+	const double* d = im.hinv;
+	const double rx = d[0] * hx + d[1] * hy + d[2] * hz;
+	const double ry = d[3] * hx + d[4] * hy + d[5] * hz;
+	const double rz = d[6] * hx + d[7] * hy + d[8] * hz;
+	if (rz < 0) { ox = -10; oy = -10; return; }
+	const double denom = 1.0 / rz;
+	ox = rx * denom + im.w * 0.5;
+	oy = ry * denom + im.h * 0.5;
+}
+
+// interpolate (lib/imgproc.cc:135-156); false = Color::NO
+__device__ __forceinline__ bool interpolate(const float* __restrict__ img, int rows, int cols, float r, float c, float (&out)[3]) {
+	const int fr = (int)floorf(r), fc = (int)floorf(c);
+	if (fr < 0 || fc < 0 || fc + 1 >= cols || fr + 1 >= rows) return false;
+	r -= (float)fr; c -= (float)fc;
+	const float* p00 = img + ((long long)fr * cols + fc) * 3;
+	const float* p10 = p00 + (long long)cols * 3;
+	float a0 = p00[0], a1 = p00[1], a2 = p00[2];
+	if (a0 < 0) return false;
+	float b0 = p10[0], b1 = p10[1], b2 = p10[2];
+	if (b0 < 0) return false;
+	float c0 = p10[3], c1 = p10[4], c2 = p10[5];
+	if (c0 < 0) return false;
+	float d0 = p00[3], d1 = p00[4], d2 = p00[5];
+	if (d0 < 0) return false;
+	float w = (1 - r) * (1 - c);
+	float r0 = 0.f + a0 * w, r1 = 0.f + a1 * w, r2 = 0.f + a2 * w;
+	w = r * (1 - c);
+	r0 += b0 * w; r1 += b1 * w; r2 += b2 * w;
+	w = r * c;
+	r0 += c0 * w; r1 += c1 * w; r2 += c2 * w;
+	w = (1 - r) * c;
+	r0 += d0 * w; r1 += d1 * w; r2 += d2 * w;
+	out[0] = r0; out[1] = r1; out[2] = r2;
+	return true;
+}
+
+// ---- LinearBlender::run (blender.cc:24-96): thread per canvas pixel, images in index order ----
+__global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, const BlendImg* __restrict__ imgs, int n,
+		float* __restrict__ out, int H, int W, int ordered_input, int lazy) {
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (i >= H || j >= W) return;
+	const double cx = (double)j * g.resx + g.minx;
+	const double cy = (double)i * g.resy + g.miny;
+	double hx, hy, hz;
+	proj2homo(g.method, cx, cy, hx, hy, hz);
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
+	for (int k = 0; k < n; ++k) {
+		const BlendImg& im = imgs[k];
+		// non-lazy: Range::contain, inclusive (blender.cc:84); lazy: loops exclude max (blender.cc:49-51)
+		const bool in = lazy ? (i >= im.y0 && i < im.y1 && j >= im.x0 && j < im.x1)
+		                     : (i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1);
+		if (!in) continue;
+		double ox, oy;
+		space_to_image(im, hx, hy, hz, ox, oy);
+		if (ox < 0 || ox >= im.w || oy < 0 || oy >= im.h) continue;      // ImageToAdd::map_coor (blender.hh:39-44)
+		const float r = (float)oy, c = (float)ox;
+		float col[3];
+		if (!interpolate(im.data, im.h, im.w, r, c, col)) continue;
+		if (col[0] < 0) continue;
+		float w = (float)(0.5 - fabs((double)(c / (float)im.w) - 0.5));
+		if (!ordered_input) w = (float)((double)w * (0.5 - fabs((double)(r / (float)im.h) - 0.5)));
+		s0 += col[0] * w; s1 += col[1] * w; s2 += col[2] * w;
+		wsum += w;
+	}
+	float* row = out + ((long long)i * W + j) * 3;
+	if (lazy) {
+		if (wsum != 0.f) { row[0] = s0 / wsum; row[1] = s1 / wsum; row[2] = s2 / wsum; }   // blender.cc:68-70
+		else { row[0] = -1.f; row[1] = -1.f; row[2] = -1.f; }
+	} else {
+		if (wsum > 0) {            // Vector::operator/(T p) = *this * (1.0 / p), lib/geometry.hh:123-124
+			const float inv = (float)(1.0 / (double)wsum);
+			row[0] = s0 * inv; row[1] = s1 * inv; row[2] = s2 * inv;
+		} else { row[0] = -1.f; row[1] = -1.f; row[2] = -1.f; }
+	}
+}
+
+// ---- MultiBandBlender::create_first_level (multiband.cc:19-56): thread per ROI pixel ----
+__global__ void __launch_bounds__(256) k_mb_first_level(BlendGeom g, const BlendImg* __restrict__ imgs,
+		float4* __restrict__ cur, unsigned char* __restrict__ mask) {
+	const BlendImg& im = imgs[blockIdx.y];
+	const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (e >= (long long)im.rw * im.rh) return;
+	const int i = (int)(e / im.rw), j = (int)(e % im.rw);
+	const double cx = (double)(j + im.x0) * g.resx + g.minx;
+	const double cy = (double)(i + im.y0) * g.resy + g.miny;
+	double hx, hy, hz, ox, oy;
+	proj2homo(g.method, cx, cy, hx, hy, hz);
+	space_to_image(im, hx, hy, hz, ox, oy);
+	float col[3];
+	bool ok = interpolate(im.data, im.h, im.w, (float)oy, (float)ox, col);
+	if (ok) { float mn = fminf(col[0], fminf(col[1], col[2])); if (mn < 0) ok = false; }
+	float4 px;
+	if (!ok) { px = make_float4(0.f, 0.f, 0.f, 0.f); }
+	else {
+		const double x = ox / (double)im.w - 0.5, y = oy / (double)im.h - 0.5;
+		const double v = (0.5 - fabs(x)) * (0.5 - fabs(y));
+		px = make_float4(col[0], col[1], col[2], (float)((v > 0.0 ? v : 0.0) + 1e-6));
+	}
+	cur[im.roi_off + e] = px;
+	mask[im.roi_off + e] = ok ? 0 : 1;
+}
+
+// ---- update_weight_map (multiband.cc:125-143): thread per canvas pixel ----
+__global__ void __launch_bounds__(256) k_mb_weight_map(const BlendImg* __restrict__ imgs, int n, float4* __restrict__ cur, int H, int W) {
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (i >= H || j >= W) return;
+	float mx = 0.f; long long maxe = -1;
+	for (int k = 0; k < n; ++k) {
+		const BlendImg& im = imgs[k];
+		if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) continue;
+		const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
+		const float w = cur[e].w;
+		if (w > mx) { mx = w; maxe = e; }
+		cur[e].w = 0.f;
+	}
+	if (maxe >= 0) cur[maxe].w = 1.f;
+}
+
+// ---- GaussianBlur::blur<WeightedPixel> (feature/gaussian.hh:30-91): column pass then row pass,
+// replicate borders, sequential fp32 multiply-add in tap order on all 4 channels ----
+struct BlurTaps { int center; float k[2 * OP_MAX_KCENTER + 1]; };
+
+template <bool COLS>
+__global__ void __launch_bounds__(256) k_mb_blur(const BlendImg* __restrict__ imgs, BlurTaps taps,
+		const float4* __restrict__ src, float4* __restrict__ dst) {
+	const BlendImg& im = imgs[blockIdx.y];
+	const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (e >= (long long)im.rw * im.rh) return;
+	const int i = (int)(e / im.rw), j = (int)(e % im.rw);
+	const float4* base = src + im.roi_off;
+	float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+	const int C = taps.center;
+	for (int k = -C; k <= C; ++k) {
+		float4 v;
+		if (COLS) { int ii = i + k; ii = ii < 0 ? 0 : (ii > im.rh - 1 ? im.rh - 1 : ii); v = base[(long long)ii * im.rw + j]; }
+		else { int jj = j + k; jj = jj < 0 ? 0 : (jj > im.rw - 1 ? im.rw - 1 : jj); v = base[(long long)i * im.rw + jj]; }
+		const float kv = taps.k[k + C];
+		t.w += v.w * kv; t.x += v.x * kv; t.y += v.y * kv; t.z += v.z * kv;
+	}
+	dst[im.roi_off + e] = t;
+}
+
+// ---- one band (multiband.cc:75-110): thread per canvas pixel; the last band also clamps (:112-121) ----
+__global__ void __launch_bounds__(256) k_mb_accumulate(const BlendImg* __restrict__ imgs, int n,
+		const float4* __restrict__ cur, const float4* __restrict__ nxt, const unsigned char* __restrict__ mask,
+		float* __restrict__ out, unsigned char* __restrict__ tmask, int H, int W, int is_last) {
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (i >= H || j >= W) return;
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
+	for (int k = 0; k < n; ++k) {
+		const BlendImg& im = imgs[k];
+		if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) continue;
+		const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
+		if (mask[e]) continue;
+		const float4 cc = cur[e];
+		if (cc.w <= 0) continue;
+		if (!is_last) {
+			const float4 cn = nxt[e];
+			s0 += (cc.x - cn.x) * cc.w; s1 += (cc.y - cn.y) * cc.w; s2 += (cc.z - cn.z) * cc.w;
+		} else {
+			s0 += cc.x * cc.w; s1 += cc.y * cc.w; s2 += cc.z * cc.w;
+		}
+		wsum += cc.w;
+	}
+	const long long pe = (long long)i * W + j;
+	float* p = out + pe * 3;
+	bool seen = tmask[pe] != 0;
+	float p0 = p[0], p1 = p[1], p2 = p[2];
+	if (!((double)wsum < 1e-6)) {
+		s0 /= wsum; s1 /= wsum; s2 /= wsum;
+		if (!seen) { p0 = s0; p1 = s1; p2 = s2; seen = true; tmask[pe] = 1; }
+		else { p0 += s0; p1 += s1; p2 += s2; }
+	}
+	if (is_last && seen) {
+		p0 = fmaxf(fminf(p0, 1.0f), 0.f); p1 = fmaxf(fminf(p1, 1.0f), 0.f); p2 = fmaxf(fminf(p2, 1.0f), 0.f);
+	}
+	p[0] = p0; p[1] = p1; p[2] = p2;
+}
+
+__global__ void __launch_bounds__(256) k_fill(float* p, long long n, float v) {
+	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+
+// ---- CylinderProject::project (stitch/warp.cc:25-44): thread per output pixel ----
+struct CylParams { double cx, cy, offx, offy, sizefactor_inv; int r; };
+__global__ void __launch_bounds__(256) k_cyl_project(CylParams P, const float* __restrict__ img, int h, int w,
+		float* __restrict__ out, int nh, int nw) {
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (i >= nh || j >= nw) return;
+	const double px = ((double)j - P.offx) * P.sizefactor_inv, py = ((double)i - P.offy) * P.sizefactor_inv;
+	const double ox = (double)P.r * tan(px) + P.cx;                 // proj_r (warp.cc:19-23)
+	const double oy = py * (double)P.r / cos(px) + P.cy;
+	float c[3] = {-1.f, -1.f, -1.f};
+	// between(a, b, c) = a >= b && a <= c - 1 (lib/utils.hh:27)
+	if (ox >= 0 && ox <= (double)(w - 1) && oy >= 0 && oy <= (double)(h - 1))
+		interpolate(img, h, w, (float)oy, (float)ox, c);
+	float* p = out + ((long long)i * nw + j) * 3;
+	p[0] = c[0]; p[1] = c[1]; p[2] = c[2];
+}
+
+// ------------------------------- host geometry (fp64, host libm) -------------------------------
+// Eigen::FullPivLU 3x3 inverse used by Homography::inverse (stitch/homography.cc:25-39)
+bool inverse3_host(const double a[9], double inv[9]) {
+	double lu[9]; memcpy(lu, a, sizeof(lu));
+	int rowt[3], colt[3], nonzero = 3; double maxpivot = 0;
+	for (int k = 0; k < 3; ++k) {
+		int br = k, bc = k; double best = -1;
+		for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j) { double v = std::fabs(lu[i * 3 + j]); if (v > best) { best = v; br = i; bc = j; } }
+		if (best == 0.0) { nonzero = k; for (int i = k; i < 3; ++i) rowt[i] = colt[i] = i; break; }
+		if (best > maxpivot) maxpivot = best;
+		rowt[k] = br; colt[k] = bc;
+		if (br != k) for (int j = 0; j < 3; ++j) std::swap(lu[k * 3 + j], lu[br * 3 + j]);
+		if (bc != k) for (int i = 0; i < 3; ++i) std::swap(lu[i * 3 + k], lu[i * 3 + bc]);
+		for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
+		for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j) lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
+	}
+	const double thr = std::fabs(maxpivot) * (DBL_EPSILON * 3);
+	int rank = 0;
+	for (int i = 0; i < nonzero; ++i) rank += (std::fabs(lu[i * 3 + i]) > thr);
+	if (rank != 3) return false;
+	for (int col = 0; col < 3; ++col) {
+		double c[3];
+		for (int i = 0; i < 3; ++i) c[i] = (i == col) ? 1.0 : 0.0;
+		for (int i = 0; i < 3; ++i) std::swap(c[i], c[rowt[i]]);
+		for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
+		for (int i = 2; i >= 0; --i) { for (int j = i + 1; j < 3; ++j) c[i] -= lu[i * 3 + j] * c[j]; c[i] /= lu[i * 3 + i]; }
+		for (int i = 2; i >= 0; --i) std::swap(c[i], c[colt[i]]);
+		for (int i = 0; i < 3; ++i) inv[i * 3 + col] = c[i];
+	}
+	return true;
+}
+
+void htrans_host(const double* d, double x, double y, double z, double out[3]) {
+	out[0] = d[0] * x + d[1] * y + d[2] * z;
+	out[1] = d[3] * x + d[4] * y + d[5] * z;
+	out[2] = d[6] * x + d[7] * y + d[8] * z;
+}
+void homo2proj_host(int method, const double h[3], double out[2]) {   // projection.hh:16-18,33-36,48-51
+	if (method == 0) { out[0] = h[0] / h[2]; out[1] = h[1] / h[2]; }
+	else if (method == 1) { out[0] = std::atan2(h[0], h[2]); out[1] = h[1] / (std::hypot(h[0], h[2])); }
+	else { out[0] = std::atan2(h[0], h[2]); out[1] = std::atan2(h[1], std::hypot(h[0], h[2])); }
+}
+
+void roi_of(const op_blend_geom* g, const double* range, int roi[4]) {   // Coor(double, double) truncation
+	roi[0] = (int)((range[0] - g->proj_min[0]) / g->resolution[0]);
+	roi[1] = (int)((range[1] - g->proj_min[1]) / g->resolution[1]);
+	roi[2] = (int)((range[2] - g->proj_min[0]) / g->resolution[0]);
+	roi[3] = (int)((range[3] - g->proj_min[1]) / g->resolution[1]);
+}
+
+// GaussCache (feature/gaussian.cc:17-40)
+int gauss_taps(float sigma, int window_factor, BlurTaps& t) {
+	int kw = (int)(std::ceil(0.3 * (sigma / 2 - 1) + 0.8) * window_factor);
+	if (kw % 2 == 0) kw++;
+	const int center = kw / 2;
+	if (center > OP_MAX_KCENTER || kw < 1) return -1;
+	float* kernel = &t.k[center];
+	kernel[0] = 1;
+	float exp_coeff = (float)(-1.0 / (sigma * sigma * 2)), wsum = 1;
+	for (int i = 1; i <= center; i++)
+		wsum += (kernel[i] = std::exp((float)(i * i) * exp_coeff)) * 2;
+	float fac = (float)(1.0 / wsum);
+	kernel[0] = fac;
+	for (int i = 1; i <= center; i++) kernel[-i] = (kernel[i] *= fac);
+	t.center = center;
+	return 0;
+}
+
+struct CylProj { double cx, cy; int r, sizefactor; };
+CylProj cyl_projector(int w, int h, double h_factor, float focal_length) {   // warp.cc:70-75
+	CylProj p;
+	p.r = (int)(std::hypot((double)w, (double)h) * (focal_length / 43.266));
+	p.cx = w / 2; p.cy = h / 2 * h_factor;
+	p.sizefactor = p.r;
+	return p;
+}
+void cyl_proj(const CylProj& P, double px, double py, double out[2]) {       // warp.cc:13-17
+	out[0] = std::atan((px - P.cx) / P.r);
+	out[1] = (py - P.cy) / (std::hypot(px - P.cx, (double)P.r));
+}
+
+struct Freer { std::vector<void*> v; ~Freer() { for (void* p : v) if (p) hipFree(p); } };
+
+}	// namespace
+
+extern "C" {
+
+int op_blend_prepare(const op_config* cfg, int proj_method, int identity_idx, int n, const int* shapes_wh,
+		const double* homo, op_blend_geom* g, double* homo_inv, double* ranges) {
+	if (!cfg || !shapes_wh || !homo || !g || !homo_inv || !ranges || n <= 0 || identity_idx < 0 || identity_idx >= n ||
+			proj_method < 0 || proj_method > 2)
+		OP_FAIL(OP_ERR_INVALID, "op_blend_prepare: bad argument");
+	for (int i = 0; i < n; ++i)
+		if (!inverse3_host(homo + 9 * i, homo_inv + 9 * i))
+			OP_FAIL(OP_ERR_INVALID, "op_blend_prepare: homography " + std::to_string(i) + " is not invertible (homography.cc:33)");
+	const int CORNER_SAMPLE = 100;        // stitcher_image.cc:43
+	std::vector<double> cx, cy;
+	for (int i = 0; i < CORNER_SAMPLE; ++i) {
+		const double xi = (double)i / CORNER_SAMPLE - 0.5;
+		cx.push_back(xi); cy.push_back(-0.5);
+		cx.push_back(xi); cy.push_back(0.5);
+	}
+	for (int j = 0; j < CORNER_SAMPLE; ++j) {
+		const double yj = (double)j / CORNER_SAMPLE - 0.5;
+		cx.push_back(-0.5); cy.push_back(yj);
+		cx.push_back(0.5); cy.push_back(yj);
+	}
+	double pmin[2] = {DBL_MAX, DBL_MAX}, pmax[2] = {-DBL_MAX, -DBL_MAX};
+	for (int m = 0; m < n; ++m) {
+		const int w = shapes_wh[2 * m], h = shapes_wh[2 * m + 1];
+		double nmin[2] = {DBL_MAX, DBL_MAX}, nmax[2] = {-DBL_MAX, -DBL_MAX};
+		for (size_t k = 0; k < cx.size(); ++k) {
+			double hv[3], t[2];
+			htrans_host(homo + 9 * m, cx[k] * w, cy[k] * h, 1, hv);
+			homo2proj_host(proj_method, hv, t);
+			for (int c = 0; c < 2; ++c) { if (t[c] < nmin[c]) nmin[c] = t[c]; if (nmax[c] < t[c]) nmax[c] = t[c]; }
+		}
+		ranges[4 * m] = nmin[0]; ranges[4 * m + 1] = nmin[1]; ranges[4 * m + 2] = nmax[0]; ranges[4 * m + 3] = nmax[1];
+		for (int c = 0; c < 2; ++c) { if (nmin[c] < pmin[c]) pmin[c] = nmin[c]; if (pmax[c] < nmax[c]) pmax[c] = nmax[c]; }
+	}
+	g->proj_method = proj_method;
+	g->proj_min[0] = pmin[0]; g->proj_min[1] = pmin[1]; g->proj_max[0] = pmax[0]; g->proj_max[1] = pmax[1];
+	// get_final_resolution (stitcher_image.cc:79-114)
+	const int refw = shapes_wh[2 * identity_idx], refh = shapes_wh[2 * identity_idx + 1];
+	double c2[3], c1[3], p2[2], p1[2];
+	htrans_host(homo + 9 * identity_idx, refw / 2.0, refh / 2.0, 1, c2);
+	htrans_host(homo + 9 * identity_idx, -refw / 2.0, -refh / 2.0, 1, c1);
+	homo2proj_host(proj_method, c2, p2); homo2proj_host(proj_method, c1, p1);
+	double rx = p2[0] - p1[0], ry = p2[1] - p1[1];
+	if (proj_method != 0) {
+		if (rx < 0) rx = 2 * M_PI + rx;
+		if (ry < 0) ry = M_PI + ry;
+	}
+	double resx = std::fabs(rx) / (double)refw, resy = std::fabs(ry) / (double)refh;
+	const double tsx = (pmax[0] - pmin[0]) / resx, tsy = (pmax[1] - pmin[1]) / resy;
+	const double max_edge = std::max(tsx, tsy);
+	if (max_edge > 80000 || tsx * tsy > 1e9)
+		OP_FAIL(OP_ERR_INVALID, "Target size too large. Looks like a stitching failure!");   // stitcher_image.cc:105-106
+	if (max_edge > cfg->MAX_OUTPUT_SIZE) {
+		const float ratio = (float)(max_edge / cfg->MAX_OUTPUT_SIZE);
+		resx *= ratio; resy *= ratio;
+	}
+	g->resolution[0] = resx; g->resolution[1] = resy;
+	return OP_OK;
+}
+
+int op_blend_canvas_dims(const op_blend_geom* g, const op_blend_image* imgs, int n, int* h, int* w) {
+	if (!g || !imgs || n <= 0 || !h || !w) OP_FAIL(OP_ERR_INVALID, "op_blend_canvas_dims: bad argument");
+	int tx = 0, ty = 0;       // Coor target_size{0,0}; update_max(bottom_right) (blender.cc:21)
+	for (int i = 0; i < n; ++i) {
+		int roi[4]; roi_of(g, imgs[i].range, roi);
+		tx = std::max(tx, roi[2]); ty = std::max(ty, roi[3]);
+	}
+	*h = ty; *w = tx;
+	return OP_OK;
+}
+
+int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op_blend_image* imgs, int n, op_canvas** out) {
+	if (!ctx || !cfg || !g || !imgs || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_blend: bad argument");
+	if (g->proj_method < 0 || g->proj_method > 2) OP_FAIL(OP_ERR_INVALID, "op_blend: bad projection method");
+	if (!(g->resolution[0] > 0) || !(g->resolution[1] > 0)) OP_FAIL(OP_ERR_INVALID, "op_blend: resolution must be positive");
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	int H, W;
+	int rc = op_blend_canvas_dims(g, imgs, n, &H, &W);
+	if (rc != OP_OK) return rc;
+	if (H <= 0 || W <= 0) OP_FAIL(OP_ERR_INVALID, "op_blend: empty canvas");
+	Freer fr;
+	std::vector<BlendImg> h_imgs(n);
+	long long roi_total = 0; long long max_roi = 0;
+	for (int k = 0; k < n; ++k) {
+		const op_blend_image& s = imgs[k];
+		if (!s.data || s.h < 2 || s.w < 2) OP_FAIL(OP_ERR_INVALID, "op_blend: bad image " + std::to_string(k));
+		BlendImg& b = h_imgs[k];
+		b.h = s.h; b.w = s.w;
+		if (s.on_device) b.data = s.data;
+		else {
+			float* d = nullptr;
+			HIPCHK(hipMalloc(&d, sizeof(float) * 3 * (size_t)s.h * s.w)); fr.v.push_back(d);
+			HIPCHK(hipMemcpyAsync(d, s.data, sizeof(float) * 3 * (size_t)s.h * s.w, hipMemcpyHostToDevice, st));
+			b.data = d;
+		}
+		int roi[4]; roi_of(g, s.range, roi);
+		if (roi[0] < 0 || roi[1] < 0 || roi[2] < roi[0] || roi[3] < roi[1]) OP_FAIL(OP_ERR_INVALID, "op_blend: image range outside proj_range");
+		b.x0 = roi[0]; b.y0 = roi[1]; b.x1 = roi[2]; b.y1 = roi[3];
+		memcpy(b.hinv, s.homo_inv, sizeof(b.hinv));
+		b.rw = roi[2] - roi[0] + 1; b.rh = roi[3] - roi[1] + 1;      // Range::width/height, inclusive
+		b.roi_off = roi_total; roi_total += (long long)b.rw * b.rh;
+		max_roi = std::max(max_roi, (long long)b.rw * b.rh);
+	}
+	BlendImg* d_imgs = nullptr;
+	HIPCHK(hipMalloc(&d_imgs, sizeof(BlendImg) * n)); fr.v.push_back(d_imgs);
+	HIPCHK(hipMemcpyAsync(d_imgs, h_imgs.data(), sizeof(BlendImg) * n, hipMemcpyHostToDevice, st));
+	op_canvas* cv = new op_canvas;
+	cv->h = H; cv->w = W; cv->device = ctx->device;
+	if (hipMalloc(&cv->data, sizeof(float) * 3 * (size_t)H * W) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_blend: canvas allocation failed"); }
+	const BlendGeom bg{g->proj_method, g->proj_min[0], g->proj_min[1], g->resolution[0], g->resolution[1]};
+	const dim3 cgrid((W + 63) / 64, (H + 3) / 4);
+#define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	hipFree(cv->data); delete cv; return OP_ERR_HIP; } } while (0)
+	if (cfg->MULTIBAND <= 0) {
+		ProfScope ps(ctx, "blend linear");
+		hipLaunchKernelGGL(k_blend_linear, cgrid, dim3(256), 0, st, bg, d_imgs, n, cv->data, H, W, cfg->ORDERED_INPUT, cfg->LAZY_READ);
+		BCHK(hipGetLastError());
+	} else {
+		const int L = cfg->MULTIBAND;
+		float4 *cur = nullptr, *nxt = nullptr, *tmp = nullptr; unsigned char *mask = nullptr, *tmask = nullptr;
+		BCHK(hipMalloc(&cur, sizeof(float4) * roi_total)); fr.v.push_back(cur);
+		BCHK(hipMalloc(&nxt, sizeof(float4) * roi_total)); fr.v.push_back(nxt);
+		BCHK(hipMalloc(&tmp, sizeof(float4) * roi_total)); fr.v.push_back(tmp);
+		BCHK(hipMalloc(&mask, roi_total)); fr.v.push_back(mask);
+		BCHK(hipMalloc(&tmask, (size_t)H * W)); fr.v.push_back(tmask);
+		BCHK(hipMemsetAsync(tmask, 0, (size_t)H * W, st));
+		const dim3 rgrid((unsigned)((max_roi + 255) / 256), n);
+		{ ProfScope ps(ctx, "multiband first level");
+		  hipLaunchKernelGGL(k_mb_first_level, rgrid, dim3(256), 0, st, bg, d_imgs, cur, mask);
+		  BCHK(hipGetLastError());
+		  hipLaunchKernelGGL(k_mb_weight_map, cgrid, dim3(256), 0, st, d_imgs, n, cur, H, W);
+		  BCHK(hipGetLastError());
+		  const long long ne = (long long)H * W * 3;
+		  hipLaunchKernelGGL(k_fill, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, cv->data, ne, -1.f);   // fill(target, Color::NO)
+		  BCHK(hipGetLastError()); }
+		for (int level = 0; level < L; ++level) {
+			const int is_last = (level == L - 1);
+			if (!is_last) {
+				ProfScope ps(ctx, "multiband blur");
+				BlurTaps taps; memset(&taps, 0, sizeof(taps));
+				if (gauss_taps((float)(std::sqrt(level * 2 + 1.0) * 4), cfg->GAUSS_WINDOW_FACTOR, taps) != 0) {
+					hipFree(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
+				}
+				hipLaunchKernelGGL(k_mb_blur<true>, rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
+				BCHK(hipGetLastError());
+				hipLaunchKernelGGL(k_mb_blur<false>, rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
+				BCHK(hipGetLastError());
+			}
+			{ ProfScope ps(ctx, "multiband band");
+			  hipLaunchKernelGGL(k_mb_accumulate, cgrid, dim3(256), 0, st, d_imgs, n, cur, nxt, mask, cv->data, tmask, H, W, is_last);
+			  BCHK(hipGetLastError()); }
+			std::swap(cur, nxt);
+		}
+	}
+	BCHK(hipStreamSynchronize(st));
+#undef BCHK
+	resolve_profile(ctx);
+	*out = cv;
+	return OP_OK;
+}
+
+int op_canvas_dims(const op_canvas* c, int* h, int* w) {
+	if (!c || !h || !w) OP_FAIL(OP_ERR_INVALID, "op_canvas_dims: bad argument");
+	*h = c->h; *w = c->w; return OP_OK;
+}
+const float* op_canvas_device(const op_canvas* c) { return c ? c->data : nullptr; }
+int op_canvas_copy(op_ctx* ctx, const op_canvas* c, float* host) {
+	if (!ctx || !c || !host) OP_FAIL(OP_ERR_INVALID, "op_canvas_copy: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemcpyAsync(host, c->data, sizeof(float) * 3 * (size_t)c->h * c->w, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return OP_OK;
+}
+void op_canvas_free(op_canvas* c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->data) hipFree(c->data);
+	delete c;
+}
+
+int op_cyl_warp_shape(const op_config* cfg, int w, int h, double h_factor, double* pts, int npts,
+		int* new_w, int* new_h, double* offset) {
+	if (!cfg || w < 2 || h < 2 || npts < 0 || (npts && !pts) || !new_w || !new_h || !offset)
+		OP_FAIL(OP_ERR_INVALID, "op_cyl_warp_shape: bad argument");
+	const CylProj P = cyl_projector(w, h, h_factor, cfg->FOCAL_LENGTH);
+	if (P.r <= 0) OP_FAIL(OP_ERR_INVALID, "op_cyl_warp_shape: degenerate projector radius");
+	// warp.cc:47-52 scans all w*h pixels.  x = atan((j-cx)/r) does not depend on i, and for a fixed
+	// j the quotient y = (i-cy)/hypot(j-cx, r) is monotone in i in floating point as well (one
+	// subtraction and one division by a fixed positive number), so rows 0 and h-1 hold both
+	// extremes of every column: 2w evaluations give the identical min/max.
+	double mn[2] = {DBL_MAX, DBL_MAX}, mx[2] = {0, 0};
+	for (int j = 0; j < w; ++j) for (int e = 0; e < 2; ++e) {
+		double c[2]; cyl_proj(P, j, e ? h - 1 : 0, c);
+		for (int q = 0; q < 2; ++q) { if (c[q] < mn[q]) mn[q] = c[q]; if (mx[q] < c[q]) mx[q] = c[q]; }
+	}
+	for (int q = 0; q < 2; ++q) { mx[q] = mx[q] * P.sizefactor; mn[q] = mn[q] * P.sizefactor; }
+	const double rsx = mx[0] - mn[0], rsy = mx[1] - mn[1];
+	offset[0] = mn[0] * (-1); offset[1] = mn[1] * (-1);
+	const int sx = (int)rsx, sy = (int)rsy;
+	for (int k = 0; k < npts; ++k) {              // warp.cc:59-65
+		double c[2];
+		cyl_proj(P, pts[2 * k] + w / 2, pts[2 * k + 1] + h / 2, c);
+		pts[2 * k] = c[0] * P.sizefactor + offset[0];
+		pts[2 * k + 1] = c[1] * P.sizefactor + offset[1];
+		pts[2 * k] -= sx / 2;
+		pts[2 * k + 1] -= sy / 2;
+	}
+	*new_w = sx; *new_h = sy;
+	return OP_OK;
+}
+
+int op_cyl_warp(op_ctx* ctx, const op_config* cfg, const op_image* img, double h_factor, op_canvas** out) {
+	if (!ctx || !cfg || !img || !img->data || !out) OP_FAIL(OP_ERR_INVALID, "op_cyl_warp: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	int nw, nh; double off[2];
+	int rc = op_cyl_warp_shape(cfg, img->w, img->h, h_factor, nullptr, 0, &nw, &nh, off);
+	if (rc != OP_OK) return rc;
+	if (nw <= 0 || nh <= 0) OP_FAIL(OP_ERR_INVALID, "op_cyl_warp: empty output");
+	Freer fr;
+	const float* src = img->data;
+	if (!img->on_device) {
+		float* d = nullptr;
+		HIPCHK(hipMalloc(&d, sizeof(float) * 3 * (size_t)img->h * img->w)); fr.v.push_back(d);
+		HIPCHK(hipMemcpyAsync(d, img->data, sizeof(float) * 3 * (size_t)img->h * img->w, hipMemcpyHostToDevice, st));
+		src = d;
+	}
+	const CylProj P = cyl_projector(img->w, img->h, h_factor, cfg->FOCAL_LENGTH);
+	op_canvas* cv = new op_canvas;
+	cv->h = nh; cv->w = nw; cv->device = ctx->device;
+	if (hipMalloc(&cv->data, sizeof(float) * 3 * (size_t)nh * nw) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_cyl_warp: allocation failed"); }
+	const CylParams cp{P.cx, P.cy, off[0], off[1], 1.0 / P.sizefactor, P.r};
+	{ ProfScope ps(ctx, "cylinder warp");
+	  hipLaunchKernelGGL(k_cyl_project, dim3((nw + 63) / 64, (nh + 3) / 4), dim3(256), 0, st, cp, src, img->h, img->w, cv->data, nh, nw); }
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) { hipFree(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_cyl_warp: ") + hipGetErrorString(e)); }
+	resolve_profile(ctx);
+	*out = cv;
+	return OP_OK;
+}
+
+}	// extern "C"

@@ -49,6 +49,16 @@ class OpImage(C.Structure):
     _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int)]
 
 
+class OpBlendImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int),
+                ("homo_inv", C.c_double * 9), ("range", C.c_double * 4)]
+
+
+class OpBlendGeom(C.Structure):
+    _fields_ = [("proj_method", C.c_int), ("proj_min", C.c_double * 2), ("proj_max", C.c_double * 2),
+                ("resolution", C.c_double * 2)]
+
+
 _lib = None
 
 
@@ -141,6 +151,18 @@ def lib():
     L.op_ransac_inliers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.op_ransac_best.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.op_ransac_free.argtypes = [C.c_void_p]
+    L.op_blend_prepare.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.POINTER(OpBlendGeom), C.c_void_p, C.c_void_p]
+    L.op_blend_canvas_dims.argtypes = [C.POINTER(OpBlendGeom), C.POINTER(OpBlendImage), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_blend.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpBlendGeom), C.POINTER(OpBlendImage), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_canvas_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_canvas_device.restype = C.c_void_p
+    L.op_canvas_device.argtypes = [C.c_void_p]
+    L.op_canvas_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.op_canvas_free.argtypes = [C.c_void_p]
+    L.op_cyl_warp_shape.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    L.op_cyl_warp.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_double, C.POINTER(C.c_void_p)]
     _lib = L
     return L
 
@@ -452,3 +474,86 @@ def match_pairs(ctx: Context, cfg, feats: Features, pairs):
     finally:
         L.op_matches_free(h)
     return out
+
+
+class Canvas:
+    """``op_canvas``: device-resident H x W x 3 fp32 result of a blend / warp."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx; self.handle = handle
+        h, w = C.c_int(), C.c_int()
+        check(lib().op_canvas_dims(handle, C.byref(h), C.byref(w)))
+        self.h, self.w = h.value, w.value
+
+    @property
+    def device_ptr(self):
+        return lib().op_canvas_device(self.handle)
+
+    def numpy(self):
+        out = np.empty((self.h, self.w, 3), np.float32)
+        check(lib().op_canvas_copy(self.ctx.handle, self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def free(self):
+        if self.handle:
+            lib().op_canvas_free(self.handle); self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def blend_prepare(cfg, shapes_wh, homos, proj_method, identity_idx):
+    """Host geometry of ``ConnectedImages`` (calc_inverse_homo, update_proj_range,
+    get_final_resolution: stitcher_image.cc:36-114) -> (OpBlendGeom, homo_inv (n,9), ranges (n,4))."""
+    sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+    n = len(sh)
+    homo = np.ascontiguousarray(np.asarray(homos, np.float64).reshape(n, 9))
+    ccfg = OpConfig.from_config(cfg)
+    g = OpBlendGeom(); hinv = np.zeros((n, 9), np.float64); ranges = np.zeros((n, 4), np.float64)
+    check(lib().op_blend_prepare(C.byref(ccfg), int(proj_method), int(identity_idx), n, sh.ctypes.data_as(C.c_void_p),
+                                 homo.ctypes.data_as(C.c_void_p), C.byref(g), hinv.ctypes.data_as(C.c_void_p),
+                                 ranges.ctypes.data_as(C.c_void_p)))
+    return g, hinv, ranges
+
+
+def blend(ctx: Context, cfg, images, homos, proj_method, identity_idx) -> Canvas:
+    """``ConnectedImages::blend()`` (stitcher_image.cc:116-155) on the device.
+    images: numpy HWC float32 arrays or (device_ptr, h, w); homos: n x 3 x 3 ImageComponent::homo."""
+    n = len(images)
+    arr_img, keep = _mk_images(images)
+    shapes = [(arr_img[i].w, arr_img[i].h) for i in range(n)]
+    g, hinv, ranges = blend_prepare(cfg, shapes, homos, proj_method, identity_idx)
+    arr = (OpBlendImage * n)()
+    for i in range(n):
+        arr[i].data = arr_img[i].data; arr[i].h = arr_img[i].h; arr[i].w = arr_img[i].w; arr[i].on_device = arr_img[i].on_device
+        for k in range(9):
+            arr[i].homo_inv[k] = hinv[i, k]
+        for k in range(4):
+            arr[i].range[k] = ranges[i, k]
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(lib().op_blend(ctx.handle, C.byref(ccfg), C.byref(g), arr, n, C.byref(h)))
+    del keep
+    return Canvas(ctx, h)
+
+
+def cyl_warp_shape(cfg, w, h, h_factor, pts=None):
+    """Host part of ``CylinderWarper::warp`` -> (new_w, new_h, offset (2,), warped centred pts)."""
+    ccfg = OpConfig.from_config(cfg)
+    p = np.ascontiguousarray(pts, np.float64).reshape(-1, 2).copy() if pts is not None else np.zeros((0, 2))
+    nw, nh = C.c_int(), C.c_int(); off = np.zeros(2)
+    check(lib().op_cyl_warp_shape(C.byref(ccfg), int(w), int(h), float(h_factor), p.ctypes.data_as(C.c_void_p) if len(p) else None,
+                                  len(p), C.byref(nw), C.byref(nh), off.ctypes.data_as(C.c_void_p)))
+    return nw.value, nh.value, off, p
+
+
+def cyl_warp(ctx: Context, cfg, image, h_factor) -> Canvas:
+    arr, keep = _mk_images([image])
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(lib().op_cyl_warp(ctx.handle, C.byref(ccfg), arr, float(h_factor), C.byref(h)))
+    del keep
+    return Canvas(ctx, h)

@@ -119,3 +119,35 @@ CONFIGS = {
     "cfg3_13x1500x1112": dict(n=13, h=1112, w=1500, seed=33, overlap=0.40),
     "cfg4_38x1300x867": dict(n=38, h=867, w=1300, seed=38, overlap=0.45, rows=2, shuffle=True),
 }
+
+
+def pano_scene(n: int, h: int, w: int, seed: int, proj: str = "flat", focal: float = None, step: float = 0.55):
+    """A rendering test scene: ``n`` h x w views of one world plus the homographies
+    (``ImageComponent::homo``, centred image plane -> space, stitch/stitcher_image.hh:38-42) a
+    successful stitch would have estimated.
+
+    proj = "flat": translations with a small rotation / perspective jitter (TRANS / plain homography
+    mode); "camera": K^-1 then a yaw/pitch/roll rotation (ESTIMATE_CAMERA / CYLINDER modes, where the
+    homography maps pixels to rays).  Views are cut from a common world so overlaps agree.
+    """
+    rng = np.random.default_rng(seed)
+    dx = int(w * step)
+    world = make_world(seed, h + 80, dx * (n - 1) + w + 80, work_scale=1600.0 / (h + w), density=500.0)
+    views, homos = [], []
+    f = float(focal or (0.9 * w))
+    for i in range(n):
+        top = 40 + int(rng.integers(-12, 13)); left = 40 + i * dx
+        views.append(np.ascontiguousarray(world[top: top + h, left: left + w]))
+        jit = np.deg2rad(rng.uniform(-1.5, 1.5))
+        if proj == "flat":
+            H = np.array([[np.cos(jit), -np.sin(jit), (i - n // 2) * dx],
+                          [np.sin(jit), np.cos(jit), top - 40.0],
+                          [rng.uniform(-5e-5, 5e-5), rng.uniform(-5e-5, 5e-5), 1.0]])
+        else:
+            yaw = (i - n // 2) * dx / f; pitch = (top - 40.0) / f; roll = jit
+            Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+            Rx = np.array([[1, 0, 0], [0, np.cos(pitch), np.sin(pitch)], [0, -np.sin(pitch), np.cos(pitch)]])
+            Rz = np.array([[np.cos(roll), -np.sin(roll), 0], [np.sin(roll), np.cos(roll), 0], [0, 0, 1]])
+            H = Ry @ Rx @ Rz @ np.diag([1.0 / f, 1.0 / f, 1.0])
+        homos.append(H)
+    return views, np.stack(homos)

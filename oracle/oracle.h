@@ -83,6 +83,31 @@ int orc_ransac(const int* match, int m, const double* kp1, int nk1, const double
 		float inlier_in_match_ratio, float inlier_in_points_ratio, unsigned seed,
 		float* confidence, double* homo_out, int* inliers, int* n_inliers, int* best_hyp, int* best_count);
 
+/* ---- warp + blend: ConnectedImages::blend (stitch/stitcher_image.cc:116-155) with
+ * LinearBlender (stitch/blender.cc:24-96) or MultiBandBlender (stitch/multiband.cc:19-151) ---- */
+typedef struct {
+	const float* data;	/* H x W x 3 fp32, Color::NO = -1 allowed */
+	int h, w;
+	double homo_inv[9];	/* ImageComponent::homo_inv (stitcher_image.hh:40-42) */
+	double range[4];	/* ImageComponent::range: min.x, min.y, max.x, max.y (projection coords) */
+} orc_blend_image;
+typedef struct {
+	int proj_method;	/* ConnectedImages::ProjectionMethod: 0 flat, 1 cylindrical, 2 spherical */
+	double proj_min[2], proj_max[2];	/* proj_range */
+	double resolution[2];			/* get_final_resolution() */
+} orc_blend_geom;
+/* calc_inverse_homo + update_proj_range + get_final_resolution (stitcher_image.cc:36-114);
+ * homo: n x 9 (centred image plane -> space); fills g, homo_inv (n x 9), ranges (n x 4) */
+int orc_blend_prepare(int proj_method, int identity_idx, int n, const int* shapes_wh, const double* homo,
+		int max_output_size, orc_blend_geom* g, double* homo_inv, double* ranges);
+int orc_blend_dims(const orc_blend_geom* g, const orc_blend_image* imgs, int n, int* h, int* w);
+int orc_blend_linear(const orc_blend_geom* g, const orc_blend_image* imgs, int n, int ordered_input, int lazy_read, float* out);
+int orc_blend_multiband(const orc_blend_geom* g, const orc_blend_image* imgs, int n, int band_level, int window_factor, float* out);
+/* CylinderWarper::warp (stitch/warp.hh:47-55, warp.cc:25-75): shape/keypoints, then pixels */
+int orc_cyl_shape(int w, int h, double h_factor, float focal_length, double* pts, int npts,
+		int* new_w, int* new_h, double* offset);
+int orc_cyl_project(const float* img, int h, int w, double h_factor, float focal_length, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,8 @@
 #include "feature/gaussian.hh"
 #include "stitch/transform_estimate.hh"
 #include "stitch/match_info.hh"
+#include "stitch/stitcher_image.hh"
+#include "stitch/warp.hh"
 
 using namespace pano;
 using namespace config;
@@ -273,5 +275,70 @@ int ref_gauss_kernel(float sigma, float* out) {
 	for (int i = 0; i < g.kw; ++i) out[i] = g.kernel[i - g.kw / 2];
 	return g.kw;
 }
+
+// ---- ConnectedImages::blend (stitch/stitcher_image.cc:116-155) on in-memory images ----
+// homo: n x 9 (ImageComponent::homo).  Runs calc_inverse_homo, update_proj_range, blend with the
+// blender the config selects (MULTIBAND / LAZY_READ / ORDERED_INPUT globals).
+struct BlendRun {
+	std::vector<std::unique_ptr<ImageRef>> refs;
+	ConnectedImages bundle;
+	Mat32f result;
+	Vec2D resolution;
+};
+void* ref_blend_new(int proj_method, int identity_idx, int n, const float* const* rgb, const int* hw, const double* homo) {
+	BlendRun* r = new BlendRun;
+	r->bundle.proj_method = (ConnectedImages::ProjectionMethod)proj_method;
+	r->bundle.identity_idx = identity_idx;
+	for (int i = 0; i < n; ++i) {
+		r->refs.emplace_back(new ImageRef("<memory>"));
+		ImageRef* ir = r->refs.back().get();
+		ir->img = new Mat32f(wrap_rgb(rgb[i], hw[2 * i], hw[2 * i + 1]));	// load() is then a no-op (imageref.hh:25-26)
+		ir->_width = hw[2 * i + 1]; ir->_height = hw[2 * i];
+		r->bundle.component.emplace_back(ir);
+		for (int k = 0; k < 9; ++k) r->bundle.component.back().homo[k] = homo[9 * i + k];
+	}
+	r->bundle.calc_inverse_homo();
+	r->bundle.update_proj_range();
+	r->resolution = r->bundle.get_final_resolution();
+	r->result = r->bundle.blend();
+	return r;
+}
+void ref_blend_dims(void* hd, int* h, int* w) { BlendRun* r = (BlendRun*)hd; *h = r->result.height(); *w = r->result.width(); }
+void ref_blend_get(void* hd, float* out) {
+	BlendRun* r = (BlendRun*)hd;
+	memcpy(out, r->result.ptr(), sizeof(float) * (size_t)r->result.height() * r->result.width() * 3);
+}
+// geom: proj_min.xy, proj_max.xy, resolution.xy ; ranges: n x 4 ; homo_inv: n x 9
+void ref_blend_meta(void* hd, double* geom, double* ranges, double* homo_inv) {
+	BlendRun* r = (BlendRun*)hd;
+	geom[0] = r->bundle.proj_range.min.x; geom[1] = r->bundle.proj_range.min.y;
+	geom[2] = r->bundle.proj_range.max.x; geom[3] = r->bundle.proj_range.max.y;
+	geom[4] = r->resolution.x; geom[5] = r->resolution.y;
+	for (size_t i = 0; i < r->bundle.component.size(); ++i) {
+		auto& c = r->bundle.component[i];
+		ranges[4 * i] = c.range.min.x; ranges[4 * i + 1] = c.range.min.y;
+		ranges[4 * i + 2] = c.range.max.x; ranges[4 * i + 3] = c.range.max.y;
+		for (int k = 0; k < 9; ++k) homo_inv[9 * i + k] = c.homo_inv[k];
+	}
+}
+void ref_blend_free(void* hd) { delete (BlendRun*)hd; }
+
+// ---- CylinderWarper::warp (stitch/warp.hh:47-55) ----
+struct CylRun { Mat32f mat; std::vector<Vec2D> pts; };
+void* ref_cyl_warp_new(const float* rgb, int h, int w, double h_factor, const double* pts, int npts) {
+	CylRun* r = new CylRun;
+	r->mat = wrap_rgb(rgb, h, w);
+	for (int i = 0; i < npts; ++i) r->pts.emplace_back(pts[2 * i], pts[2 * i + 1]);
+	CylinderWarper warper(h_factor);
+	warper.warp(r->mat, r->pts);
+	return r;
+}
+void ref_cyl_warp_dims(void* hd, int* h, int* w) { CylRun* r = (CylRun*)hd; *h = r->mat.height(); *w = r->mat.width(); }
+void ref_cyl_warp_get(void* hd, float* out, double* pts) {
+	CylRun* r = (CylRun*)hd;
+	memcpy(out, r->mat.ptr(), sizeof(float) * (size_t)r->mat.height() * r->mat.width() * 3);
+	for (size_t i = 0; i < r->pts.size(); ++i) { pts[2 * i] = r->pts[i].x; pts[2 * i + 1] = r->pts[i].y; }
+}
+void ref_cyl_warp_free(void* hd) { delete (CylRun*)hd; }
 
 }	// extern "C"

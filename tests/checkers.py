@@ -48,6 +48,16 @@ class OrcCfg(C.Structure):
         return c
 
 
+class OrcBlendImage(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("h", C.c_int), ("w", C.c_int),
+                ("homo_inv", C.c_double * 9), ("range", C.c_double * 4)]
+
+
+class OrcBlendGeom(C.Structure):
+    _fields_ = [("proj_method", C.c_int), ("proj_min", C.c_double * 2), ("proj_max", C.c_double * 2),
+                ("resolution", C.c_double * 2)]
+
+
 class SiftStages:
     """All intermediates of one staged SIFT run, copied to numpy."""
 
@@ -151,8 +161,58 @@ class Oracle(_StagedBase):
                                    C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_uint,
                                    C.POINTER(C.c_float), _f64p, _i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
+        lib.orc_blend_prepare.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_void_p, _f64p, _f64p]
+        lib.orc_blend_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.orc_blend_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]
+        lib.orc_blend_multiband.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]
+        lib.orc_cyl_shape.argtypes = [C.c_int, C.c_int, C.c_double, C.c_float, _f64p, C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), _f64p]
+        lib.orc_cyl_project.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_float, _f32p]
+
     def _cp(self):
         return C.byref(self.ccfg)
+
+    def blend(self, imgs, homos, proj_method, identity_idx, cfg=None):
+        """ConnectedImages::blend over in-memory images. homos: n x 3 x 3 (ImageComponent::homo).
+        -> (canvas (H, W, 3) f32, meta dict(geom(6), ranges (n,4), homo_inv (n,9)))"""
+        cfg = cfg or self.cfg
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(im, np.float32) for im in imgs]
+        shapes = np.array([[im.shape[1], im.shape[0]] for im in imgs], np.int32)
+        homo = np.ascontiguousarray(np.asarray(homos, np.float64).reshape(n, 9))
+        geom = OrcBlendGeom(); hinv = np.zeros((n, 9), np.float64); ranges = np.zeros((n, 4), np.float64)
+        rc = self.lib.orc_blend_prepare(int(proj_method), int(identity_idx), n, shapes.reshape(-1), homo.reshape(-1),
+                                        int(cfg.MAX_OUTPUT_SIZE), C.byref(geom), hinv.reshape(-1), ranges.reshape(-1))
+        assert rc == 0, rc
+        arr = (OrcBlendImage * n)()
+        for i, im in enumerate(imgs):
+            arr[i].data = im.ctypes.data_as(C.POINTER(C.c_float)); arr[i].h = im.shape[0]; arr[i].w = im.shape[1]
+            for k in range(9):
+                arr[i].homo_inv[k] = hinv[i, k]
+            for k in range(4):
+                arr[i].range[k] = ranges[i, k]
+        h, w = C.c_int(), C.c_int()
+        self.lib.orc_blend_dims(C.byref(geom), arr, n, C.byref(h), C.byref(w))
+        out = np.empty((h.value, w.value, 3), np.float32)
+        if cfg.MULTIBAND > 0:
+            self.lib.orc_blend_multiband(C.byref(geom), arr, n, int(cfg.MULTIBAND), int(cfg.GAUSS_WINDOW_FACTOR), out.reshape(-1))
+        else:
+            self.lib.orc_blend_linear(C.byref(geom), arr, n, int(cfg.ORDERED_INPUT), int(cfg.LAZY_READ), out.reshape(-1))
+        meta = dict(geom=np.array([geom.proj_min[0], geom.proj_min[1], geom.proj_max[0], geom.proj_max[1],
+                                   geom.resolution[0], geom.resolution[1]]), ranges=ranges, homo_inv=hinv)
+        return out, meta
+
+    def cyl_warp(self, img, h_factor, pts, cfg=None):
+        """CylinderWarper(h_factor).warp(mat, kpts) -> (warped (H', W', 3), pts')"""
+        cfg = cfg or self.cfg
+        img = np.ascontiguousarray(img, np.float32)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2).copy()
+        nw, nh = C.c_int(), C.c_int(); off = np.zeros(2)
+        self.lib.orc_cyl_shape(img.shape[1], img.shape[0], float(h_factor), float(cfg.FOCAL_LENGTH),
+                               pts.reshape(-1) if len(pts) else np.zeros(2), len(pts), C.byref(nw), C.byref(nh), off)
+        out = np.empty((nh.value, nw.value, 3), np.float32)
+        self.lib.orc_cyl_project(img.reshape(-1), img.shape[0], img.shape[1], float(h_factor), float(cfg.FOCAL_LENGTH), out.reshape(-1))
+        return out, pts
 
     def ransac(self, match, kp1, kp2, shape1, shape2, seed, cfg=None):
         """TransformEstimation(...).get_transform with an injected mt19937 seed.
@@ -246,6 +306,54 @@ class Ref(_StagedBase):
         lib.ref_gauss_kernel.argtypes = [C.c_float, _f32p]
         lib.ref_ransac.argtypes = [_i32p, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                    C.POINTER(C.c_float), _f64p, _f64p, C.POINTER(C.c_int)]
+
+    def _bind_blend(self):
+        lib = self.lib
+        if getattr(self, "_blend_bound", False):
+            return
+        lib.ref_blend_new.restype = C.c_void_p
+        lib.ref_blend_new.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), _i32p, _f64p]
+        lib.ref_blend_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.ref_blend_get.argtypes = [C.c_void_p, _f32p]
+        lib.ref_blend_meta.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
+        lib.ref_blend_free.argtypes = [C.c_void_p]
+        lib.ref_cyl_warp_new.restype = C.c_void_p
+        lib.ref_cyl_warp_new.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, _f64p, C.c_int]
+        lib.ref_cyl_warp_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.ref_cyl_warp_get.argtypes = [C.c_void_p, _f32p, _f64p]
+        lib.ref_cyl_warp_free.argtypes = [C.c_void_p]
+        self._blend_bound = True
+
+    def blend(self, imgs, homos, proj_method, identity_idx):
+        """The reference's ConnectedImages::blend with the blender its config globals select."""
+        self._bind_blend()
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(im, np.float32) for im in imgs]
+        ptrs = (C.POINTER(C.c_float) * n)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in imgs])
+        hw = np.array([[im.shape[0], im.shape[1]] for im in imgs], np.int32)
+        homo = np.ascontiguousarray(np.asarray(homos, np.float64).reshape(n, 9))
+        hd = self.lib.ref_blend_new(int(proj_method), int(identity_idx), n, ptrs, hw.reshape(-1), homo.reshape(-1))
+        h, w = C.c_int(), C.c_int()
+        self.lib.ref_blend_dims(hd, C.byref(h), C.byref(w))
+        out = np.empty((h.value, w.value, 3), np.float32)
+        self.lib.ref_blend_get(hd, out.reshape(-1))
+        geom = np.zeros(6); ranges = np.zeros((n, 4)); hinv = np.zeros((n, 9))
+        self.lib.ref_blend_meta(hd, geom, ranges.reshape(-1), hinv.reshape(-1))
+        self.lib.ref_blend_free(hd)
+        return out, dict(geom=geom, ranges=ranges, homo_inv=hinv)
+
+    def cyl_warp(self, img, h_factor, pts):
+        self._bind_blend()
+        img = np.ascontiguousarray(img, np.float32)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        hd = self.lib.ref_cyl_warp_new(img.reshape(-1), img.shape[0], img.shape[1], float(h_factor),
+                                       pts.reshape(-1) if len(pts) else np.zeros(2), len(pts))
+        h, w = C.c_int(), C.c_int()
+        self.lib.ref_cyl_warp_dims(hd, C.byref(h), C.byref(w))
+        out = np.empty((h.value, w.value, 3), np.float32); po = np.zeros((max(len(pts), 1), 2))
+        self.lib.ref_cyl_warp_get(hd, out.reshape(-1), po.reshape(-1))
+        self.lib.ref_cyl_warp_free(hd)
+        return out, po[: len(pts)].copy()
 
     def set_config(self, **kv):
         for k, v in kv.items():

@@ -74,6 +74,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "match_ab.npz"), pairs=pairs,
                         n1=np.int32(len(sa.desc)), n2=np.int32(len(sb.desc)))
     print("match_ab", len(sa.desc), len(sb.desc), "->", len(pairs))
+    blend_case(ref)
+
+
+def blend_case(ref):
+    """ConnectedImages::blend of the reference on a small spherical bundle: LinearBlender
+    (LAZY_READ 0, the deterministic branch -- SURVEY F5) and MultiBandBlender(3), 1 thread."""
+    views, homos = synth.pano_scene(3, 80, 112, seed=404, proj="camera")
+    u8 = [(v * 255 + 0.5).astype(np.uint8) for v in views]
+    f32 = [u8_to_f32(v) for v in u8]
+    ref.lib.ref_set_threads(1)
+    ref.set_config(LAZY_READ=0, ORDERED_INPUT=0, MULTIBAND=0)
+    lin, meta = ref.blend(f32, homos, 2, 1)
+    ref.set_config(MULTIBAND=3)
+    mb, _ = ref.blend(f32, homos, 2, 1)
+    ref.set_config(MULTIBAND=0, LAZY_READ=1)
+    np.savez_compressed(os.path.join(HERE, "blend_sph_linear.npz"), views=np.stack(u8), homos=homos,
+                        identity_idx=np.int32(1), canvas_linear=lin, canvas_multiband3=mb,
+                        geom=meta["geom"], ranges=meta["ranges"], homo_inv=meta["homo_inv"])
+    print("blend_sph_linear", lin.shape, "covered", float((lin[..., 0] >= 0).mean()))
 
 
 if __name__ == "__main__":

@@ -72,3 +72,18 @@ def test_matcher_edge_cases(oracle):
     # identical sets: every descriptor's best is itself at distance 0 -> accepted (0 > 0.64*d is false)
     p = oracle.match_exact(a[:50], a[:50])
     assert np.array_equal(p, np.stack([np.arange(50), np.arange(50)], 1))
+
+
+def test_blend_oracle_matches_golden():
+    """oracle/blend_oracle.c against the committed output of the reference's own
+    ConnectedImages::blend (LinearBlender and MultiBandBlender(3)); runs anywhere."""
+    import os
+    from checkers import Oracle
+    from openpano_amd.config import PanoConfig
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "blend_sph_linear.npz"))
+    views = [(v.astype(np.float64) / 255.0).astype(np.float32) for v in z["views"]]
+    for key, mb in (("linear", 0), ("multiband3", 3)):
+        cfg = PanoConfig(LAZY_READ=0, MULTIBAND=mb)
+        got, meta = Oracle(cfg).blend(views, z["homos"], 2, int(z["identity_idx"]), cfg)
+        assert np.array_equal(got, z["canvas_" + key]), key
+        assert np.array_equal(meta["geom"], z["geom"]) and np.array_equal(meta["ranges"], z["ranges"])
