@@ -109,7 +109,12 @@ const float* op_features_desc_device(const op_features* f);
 const double* op_features_coor_device(const op_features* f);
 /* D2H copy of image i's K_i x 128 descriptors and K_i x 2 coordinates (either may be NULL) */
 int op_features_copy(op_ctx* ctx, const op_features* f, int i, float* desc, double* coor);
-/* build an op_features from host arrays (debug commands / tests: match without SIFT) */
+/* D2H copy of image i's K_i x 2 real_coor in [0,1) -- what SIFTDetector::do_detect_feature itself
+ * returns (feature/feature.cc:31-47) before FeatureDetector::detect_feature re-centres it (:20-28);
+ * the C++ adapter's do_detect_feature override hands these to the reference's base class */
+int op_features_copy_real(op_ctx* ctx, const op_features* f, int i, double* real);
+/* build an op_features from host arrays (debug commands / tests: match without SIFT).
+ * desc may be NULL (coordinates only: enough for op_ransac_pairs; op_match_pairs then fails) */
 int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* const* coor,
 		const int* counts, int n, op_features** out);
 /* the same from a flat DEVICE buffer (images back to back; D2D copy) -- the multi-GPU path hands

@@ -34,7 +34,7 @@ struct DescLds {
 };
 
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
-		const long long* img_offset, long long total, float* desc, double* coor) {
+		const long long* img_offset, long long total, float* desc, double* coor, double* real) {
 	__shared__ DescLds S;
 	const int lane = threadIdx.x;
 	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		if (lane == 0) {   // feature/feature.cc:23-26
 			coor[kk * 2] = (kp.rx - 0.5) * (double)p.sw;
 			coor[kk * 2 + 1] = (kp.ry - 0.5) * (double)p.sh;
+			real[kk * 2] = kp.rx; real[kk * 2 + 1] = kp.ry;      // do_detect_feature's own [0,1) output
 		}
 		__syncthreads();
 	}
@@ -182,9 +183,9 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 }	// namespace
 
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset,
-		long long total, float* desc, double* coor, hipStream_t st) {
+		long long total, float* desc, double* coor, double* real, hipStream_t st) {
 	if (total <= 0) return hipSuccess;
 	const int grid = (int)(total < 32768 ? total : 32768);
-	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, total, desc, coor);
+	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, total, desc, coor, real);
 	return hipGetLastError();
 }

@@ -113,5 +113,5 @@ hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, co
 hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
 		int* per_image /* n */, hipStream_t st);
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset /* n+1 device */,
-		long long total, float* desc, double* coor, hipStream_t st);
+		long long total, float* desc, double* coor, double* real, hipStream_t st);
 hipError_t launch_debug_math(int which, const float* x, const float* y, int n, float* out, hipStream_t st);

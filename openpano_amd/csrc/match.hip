@@ -238,6 +238,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const FeatView fv = op_features_view(f);
 	hipStream_t st = ctx->stream;
 	const long long total = fv.offsets[fv.n];
+	if (!fv.desc) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: features hold coordinates only (built without descriptors)");
 	op_matches* m = new op_matches;
 	m->npairs = npairs; m->pairs.resize(npairs);
 	if (npairs == 0 || total == 0) { *out = m; return OP_OK; }

@@ -60,13 +60,15 @@ struct op_features {
 	std::vector<int> counts;
 	std::vector<int64_t> offsets;      // n + 1
 	float* desc = nullptr;             // device, total x 128
-	double* coor = nullptr;            // device, total x 2
+	double* coor = nullptr;            // device, total x 2 (centred original-image pixels)
+	double* real = nullptr;            // device, total x 2 (real_coor in [0,1)); null when built from host/device arrays
+	bool has_desc = true;              // false: coordinates only (RANSAC-only use)
 	int device = 0;
 };
 
 struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
 FeatView op_features_view(const op_features* f) {
-	return FeatView{f->n, f->counts.data(), f->offsets.data(), f->desc, f->device};
+	return FeatView{f->n, f->counts.data(), f->offsets.data(), f->has_desc ? f->desc : nullptr, f->device};
 }
 
 struct op_sift_dump {
@@ -149,7 +151,7 @@ int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
 
 struct GroupResult {
 	std::vector<int> counts;          // per image of the group
-	float* desc = nullptr; double* coor = nullptr;   // device (hipMalloc), group-local flat
+	float* desc = nullptr; double* coor = nullptr; double* real = nullptr;   // device (hipMalloc), group-local flat
 	long long total = 0;
 };
 
@@ -238,11 +240,12 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)std::max<long long>(total, 1)));
 	HIPCHK(hipMalloc(&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
 	HIPCHK(hipMalloc(&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(hipMalloc(&res.real, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
 	{ ProfScope ps(ctx, "orientation");
 	  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
 				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st)); }
 	{ ProfScope ps(ctx, "sift descriptor");
-	  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, st)); }
+	  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, res.real, st)); }
 	HIPCHK(hipStreamSynchronize(st));     // h_off (pinned) consumed; results ready
 	resolve_profile(ctx);
 
@@ -292,7 +295,7 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 		SiftPlan plan;
 		int rc = run_group(ctx, *cfg, gi, *W, plan, results[g], nullptr);
 		if (rc != OP_OK) {
-			for (auto& r : results) { if (r.desc) hipFree(r.desc); if (r.coor) hipFree(r.coor); }
+			for (auto& r : results) { if (r.desc) hipFree(r.desc); if (r.coor) hipFree(r.coor); if (r.real) hipFree(r.real); }
 			delete f; return rc;
 		}
 		for (size_t k = 0; k < gi.size(); ++k) f->counts[groups[g].second[k]] = results[g].counts[k];
@@ -301,10 +304,11 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 	for (int i = 0; i < n; ++i) { f->offsets[i] = total; total += f->counts[i]; }
 	f->offsets[n] = total;
 	if (groups.size() == 1) {
-		f->desc = results[0].desc; f->coor = results[0].coor;
+		f->desc = results[0].desc; f->coor = results[0].coor; f->real = results[0].real;
 	} else {
 		HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
 		HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+		HIPCHK(hipMalloc(&f->real, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
 		for (size_t g = 0; g < groups.size(); ++g) {
 			long long go = 0;
 			for (size_t k = 0; k < groups[g].second.size(); ++k) {
@@ -312,12 +316,13 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 				if (c) {
 					HIPCHK(hipMemcpyAsync(f->desc + f->offsets[idx] * 128, results[g].desc + go * 128, sizeof(float) * 128 * c, hipMemcpyDeviceToDevice, ctx->stream));
 					HIPCHK(hipMemcpyAsync(f->coor + f->offsets[idx] * 2, results[g].coor + go * 2, sizeof(double) * 2 * c, hipMemcpyDeviceToDevice, ctx->stream));
+					HIPCHK(hipMemcpyAsync(f->real + f->offsets[idx] * 2, results[g].real + go * 2, sizeof(double) * 2 * c, hipMemcpyDeviceToDevice, ctx->stream));
 				}
 				go += c;
 			}
 		}
 		HIPCHK(hipStreamSynchronize(ctx->stream));
-		for (auto& r : results) { hipFree(r.desc); hipFree(r.coor); }
+		for (auto& r : results) { hipFree(r.desc); hipFree(r.coor); hipFree(r.real); }
 	}
 	*out = f;
 	return OP_OK;
@@ -341,20 +346,32 @@ int op_features_copy(op_ctx* ctx, const op_features* f, int i, float* desc, doub
 	return OP_OK;
 }
 
+int op_features_copy_real(op_ctx* ctx, const op_features* f, int i, double* real) {
+	if (!ctx || !f || i < 0 || i >= f->n || !real) OP_FAIL(OP_ERR_INVALID, "op_features_copy_real: bad argument");
+	if (!f->real) OP_FAIL(OP_ERR_INVALID, "op_features_copy_real: features were not produced by op_sift_batch");
+	HIPCHK(hipSetDevice(ctx->device));
+	const int c = f->counts[i];
+	if (c == 0) return OP_OK;
+	HIPCHK(hipMemcpyAsync(real, f->real + f->offsets[i] * 2, sizeof(double) * 2 * c, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return OP_OK;
+}
+
 int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* const* coor, const int* counts, int n, op_features** out) {
-	if (!ctx || !desc || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_from_host: bad argument");
+	if (!ctx || (!desc && !coor) || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_from_host: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
 	op_features* f = new op_features;
 	f->n = n; f->counts.assign(counts, counts + n); f->offsets.assign(n + 1, 0); f->device = ctx->device;
 	int64_t total = 0;
 	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
 	f->offsets[n] = total;
-	HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
+	f->has_desc = desc != nullptr;       // coordinates only: enough for op_ransac_pairs, rejected by op_match_pairs
+	HIPCHK(hipMalloc(&f->desc, f->has_desc ? sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1) : sizeof(float)));
 	HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
 	HIPCHK(hipMemsetAsync(f->coor, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1), ctx->stream));
 	for (int i = 0; i < n; ++i) {
 		if (!counts[i]) continue;
-		HIPCHK(hipMemcpyAsync(f->desc + f->offsets[i] * 128, desc[i], sizeof(float) * 128 * counts[i], hipMemcpyHostToDevice, ctx->stream));
+		if (f->has_desc) HIPCHK(hipMemcpyAsync(f->desc + f->offsets[i] * 128, desc[i], sizeof(float) * 128 * counts[i], hipMemcpyHostToDevice, ctx->stream));
 		if (coor && coor[i]) HIPCHK(hipMemcpyAsync(f->coor + f->offsets[i] * 2, coor[i], sizeof(double) * 2 * counts[i], hipMemcpyHostToDevice, ctx->stream));
 	}
 	HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -386,6 +403,7 @@ void op_features_free(op_features* f) {
 	hipSetDevice(f->device);
 	if (f->desc) hipFree(f->desc);
 	if (f->coor) hipFree(f->coor);
+	if (f->real) hipFree(f->real);
 	delete f;
 }
 
@@ -403,6 +421,7 @@ int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_si
 	}
 	if (res.desc) hipFree(res.desc);
 	if (res.coor) hipFree(res.coor);
+	if (res.real) hipFree(res.real);
 	if (rc != OP_OK) { d->w.release(); delete d; return rc; }
 	*out = d;
 	return OP_OK;

@@ -119,6 +119,7 @@ def lib():
     L.op_features_coor_device.restype = C.c_void_p
     L.op_features_coor_device.argtypes = [C.c_void_p]
     L.op_features_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.op_features_copy_real.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.op_features_from_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_free.argtypes = [C.c_void_p]
@@ -261,6 +262,13 @@ class Features:
         desc = np.empty((k, 128), np.float32); coor = np.empty((k, 2), np.float64)
         check(lib().op_features_copy(self.ctx.handle, self.handle, i, desc.ctypes.data_as(C.c_void_p), coor.ctypes.data_as(C.c_void_p)))
         return desc, coor
+
+    def get_real(self, i):
+        """real_coor in [0,1) of image i (what do_detect_feature itself returns, feature.cc:31-47)"""
+        k = self.count(i)
+        real = np.empty((k, 2), np.float64)
+        check(lib().op_features_copy_real(self.ctx.handle, self.handle, i, real.ctypes.data_as(C.c_void_p)))
+        return real
 
     @classmethod
     def from_host(cls, ctx, descs, coors=None):

@@ -1,0 +1,516 @@
+// pano_hip.hh -- C++ host mirror of the reference's class surface over the C-ABI
+// (include/openpano_hip.h).  Header-only; link with -lopenpano_hip.
+//
+// Two build modes, same adapter code:
+//   -DOPENPANO_WITH_REFERENCE (+ -I<reference>/src): the adapters are written against the
+//        reference's OWN types (Mat32f, Descriptor, MatchData, MatchInfo, ConnectedImages, the
+//        config:: globals) and plug into its class hierarchy -- HipSIFTDetector IS-A
+//        pano::FeatureDetector, so `feature_det.reset(new HipSIFTDetector)` in
+//        StitcherBase's constructor (stitch/stitcherbase.hh:53) is the whole integration for
+//        SIFT.  INTEGRATION.md lists every such hook; oracle/ref_dropin_test.cc exercises them
+//        against the reference's CPU classes in one process.
+//   standalone: pano_types.hh supplies value types with the same names and members.
+//
+// Interfaces mirrored (file:line under /root/reference/src):
+//   FeatureDetector::detect_feature / do_detect_feature   feature/feature.hh:42-57
+//   StitcherBase::calc_feature (batched form)             stitch/stitcherbase.cc:9-27
+//   PairWiseMatcher(feats).match(i, j)                    feature/matcher.hh:40-51
+//   TransformEstimation(...).get_transform(MatchInfo*)    stitch/transform_estimate.hh:22-31
+//   Stitcher::pairwise_match body (batched form)          stitch/stitcher.cc:66-136
+//   ConnectedImages::blend                                stitch/stitcher_image.hh:92
+//   CylinderWarper::warp                                  stitch/warp.hh:47-55
+// Error behaviour follows the reference: unrecoverable conditions end in error_exit()
+// (lib/debugutils.cc:57-60: message on stderr, exit(1)); no exception crosses the C-ABI.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "openpano_hip.h"
+
+#ifdef OPENPANO_WITH_REFERENCE
+#include "lib/config.hh"
+#include "lib/mat.h"
+#include "lib/geometry.hh"
+#include "feature/feature.hh"
+#include "feature/matcher.hh"
+#include "stitch/match_info.hh"
+#include "stitch/homography.hh"
+#include "stitch/imageref.hh"
+#include "stitch/stitcher_image.hh"
+#else
+#include "pano_types.hh"
+#endif
+
+namespace pano {
+
+// ---- errors: the reference's error_exit (lib/debugutils.cc:57-60) ----
+[[noreturn]] inline void hip_error_exit(const std::string& where) {
+	fprintf(stderr, "%s: %s\n", where.c_str(), op_last_error());
+	exit(1);
+}
+#define PANO_HIP_CHECK(expr) do { if ((expr) != OP_OK) ::pano::hip_error_exit(#expr); } while (0)
+
+// ---- config: POD snapshot of namespace config at every call (the CLI fills the globals after
+// static init, main.cc:237-292, so nothing is cached) ----
+inline op_config hip_config_snapshot() {
+	op_config c;
+	op_config_default(&c);
+	using namespace config;
+	c.SIFT_WORKING_SIZE = SIFT_WORKING_SIZE; c.NUM_OCTAVE = NUM_OCTAVE; c.NUM_SCALE = NUM_SCALE;
+	c.SCALE_FACTOR = SCALE_FACTOR; c.GAUSS_SIGMA = GAUSS_SIGMA; c.GAUSS_WINDOW_FACTOR = GAUSS_WINDOW_FACTOR;
+	c.JUDGE_EXTREMA_DIFF_THRES = JUDGE_EXTREMA_DIFF_THRES; c.CONTRAST_THRES = CONTRAST_THRES;
+	c.PRE_COLOR_THRES = PRE_COLOR_THRES; c.EDGE_RATIO = EDGE_RATIO;
+	c.CALC_OFFSET_DEPTH = CALC_OFFSET_DEPTH; c.OFFSET_THRES = OFFSET_THRES;
+	c.ORI_RADIUS = ORI_RADIUS; c.ORI_HIST_SMOOTH_COUNT = ORI_HIST_SMOOTH_COUNT;
+	c.DESC_HIST_SCALE_FACTOR = DESC_HIST_SCALE_FACTOR; c.DESC_INT_FACTOR = DESC_INT_FACTOR;
+	c.MATCH_REJECT_NEXT_RATIO = MATCH_REJECT_NEXT_RATIO;
+	c.RANSAC_ITERATIONS = RANSAC_ITERATIONS; c.RANSAC_INLIER_THRES = RANSAC_INLIER_THRES;
+	c.INLIER_IN_MATCH_RATIO = INLIER_IN_MATCH_RATIO; c.INLIER_IN_POINTS_RATIO = INLIER_IN_POINTS_RATIO;
+	c.CYLINDER = CYLINDER; c.TRANS = TRANS; c.ESTIMATE_CAMERA = ESTIMATE_CAMERA;
+	c.ORDERED_INPUT = ORDERED_INPUT; c.LAZY_READ = LAZY_READ; c.MULTIBAND = MULTIBAND;
+	c.MAX_OUTPUT_SIZE = MAX_OUTPUT_SIZE; c.FOCAL_LENGTH = FOCAL_LENGTH;
+	return c;
+}
+
+// ---- one op_ctx per host thread: the reference calls detect_feature / match concurrently from
+// OpenMP threads (stitcherbase.cc:14, stitcher.cc:106); contexts are thread-compatible ----
+class HipContext {
+	public:
+		static op_ctx* get() {
+			thread_local HipContext c;
+			return c.ctx;
+		}
+		static int& device() { static int d = 0; return d; }     // set before first use to pick a GPU
+	private:
+		op_ctx* ctx = nullptr;
+		HipContext() { PANO_HIP_CHECK(op_ctx_create(device(), nullptr, &ctx)); }
+		~HipContext() { op_ctx_destroy(ctx); }
+};
+
+// ===================================== SIFT =====================================
+#ifdef OPENPANO_WITH_REFERENCE
+#define PANO_DETECTOR_BASE : public FeatureDetector
+#define PANO_OVERRIDE override
+#else
+// the reference's base class (feature/feature.hh:42-52): detect_feature re-centres the [0,1)
+// coordinates do_detect_feature returns (feature/feature.cc:20-28)
+class FeatureDetector {
+	public:
+		FeatureDetector() = default;
+		virtual ~FeatureDetector() = default;
+		FeatureDetector(const FeatureDetector&) = delete;
+		FeatureDetector& operator=(const FeatureDetector&) = delete;
+		std::vector<Descriptor> detect_feature(const Mat32f& img) const {
+			auto ret = do_detect_feature(img);
+			for (auto& d : ret) {
+				d.coor.x = (d.coor.x - 0.5) * img.width();
+				d.coor.y = (d.coor.y - 0.5) * img.height();
+			}
+			return ret;
+		}
+		virtual std::vector<Descriptor> do_detect_feature(const Mat32f& img) const = 0;
+};
+#define PANO_DETECTOR_BASE : public FeatureDetector
+#define PANO_OVERRIDE override
+#endif
+
+// device-resident features of a whole image set: what StitcherBase keeps as `feats`, plus the
+// op_features handle so that the matcher does not re-upload descriptors
+struct HipFeatureSet {
+	op_features* handle = nullptr;
+	std::vector<std::vector<Descriptor>> feats;     // centred coordinates, like StitcherBase::feats
+	HipFeatureSet() = default;
+	HipFeatureSet(const HipFeatureSet&) = delete;
+	HipFeatureSet& operator=(const HipFeatureSet&) = delete;
+	HipFeatureSet(HipFeatureSet&& o): handle(o.handle), feats(std::move(o.feats)) { o.handle = nullptr; }
+	~HipFeatureSet() { op_features_free(handle); }
+};
+
+class HipSIFTDetector PANO_DETECTOR_BASE {
+	public:
+		// SIFTDetector::do_detect_feature (feature/feature.cc:31-47): [0,1) coordinates
+		std::vector<Descriptor> do_detect_feature(const Mat32f& mat) const PANO_OVERRIDE {
+			op_ctx* ctx = HipContext::get();
+			const op_config cfg = hip_config_snapshot();
+			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0};
+			if (mat.channels() != 3) { fprintf(stderr, "HipSIFTDetector: image must have 3 channels\n"); exit(1); }
+			op_features* f = nullptr;
+			PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, &im, 1, &f));
+			const int k = op_features_count(f, 0);
+			std::vector<float> desc((size_t)k * 128);
+			std::vector<double> real((size_t)k * 2);
+			if (k) {
+				PANO_HIP_CHECK(op_features_copy(ctx, f, 0, desc.data(), nullptr));
+				PANO_HIP_CHECK(op_features_copy_real(ctx, f, 0, real.data()));
+			}
+			op_features_free(f);
+			std::vector<Descriptor> ret(k);
+			for (int i = 0; i < k; ++i) {
+				ret[i].coor = Vec2D(real[2 * i], real[2 * i + 1]);
+				ret[i].descriptor.assign(desc.begin() + (size_t)i * 128, desc.begin() + (size_t)(i + 1) * 128);
+			}
+			return ret;
+		}
+
+		// StitcherBase::calc_feature (stitch/stitcherbase.cc:9-27) as ONE batched device call:
+		// all images in one launch series, descriptors left resident for the matcher.
+		HipFeatureSet calc_feature(const std::vector<const Mat32f*>& imgs) const {
+			op_ctx* ctx = HipContext::get();
+			const op_config cfg = hip_config_snapshot();
+			std::vector<op_image> ims;
+			for (auto* m : imgs) ims.push_back(op_image{m->ptr(), m->rows(), m->cols(), 0});
+			HipFeatureSet fs;
+			PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, ims.data(), (int)ims.size(), &fs.handle));
+			fs.feats.resize(imgs.size());
+			for (size_t k = 0; k < imgs.size(); ++k) {
+				const int n = op_features_count(fs.handle, (int)k);
+				if (n == 0) {    // stitcherbase.cc:20-21
+					fprintf(stderr, "Cannot find feature in image %d!\n", (int)k);
+					exit(1);
+				}
+				std::vector<float> desc((size_t)n * 128);
+				std::vector<double> coor((size_t)n * 2);
+				PANO_HIP_CHECK(op_features_copy(ctx, fs.handle, (int)k, desc.data(), coor.data()));
+				fs.feats[k].resize(n);
+				for (int i = 0; i < n; ++i) {
+					fs.feats[k][i].coor = Vec2D(coor[2 * i], coor[2 * i + 1]);
+					fs.feats[k][i].descriptor.assign(desc.begin() + (size_t)i * 128, desc.begin() + (size_t)(i + 1) * 128);
+				}
+			}
+			return fs;
+		}
+};
+
+// ===================================== MATCH =====================================
+// Same public signature as the reference's PairWiseMatcher (feature/matcher.hh:40-51).  match()
+// may be called concurrently (stitcher.cc:106-109): the first call matches the whole task list
+// in one device launch series, later calls are lookups.
+class HipPairWiseMatcher {
+	public:
+		explicit HipPairWiseMatcher(const std::vector<std::vector<Descriptor>>& feats): feats(feats) {
+			if (feats.empty() || feats.at(0).empty()) { fprintf(stderr, "PairWiseMatcher: no features\n"); exit(1); }
+			upload();
+		}
+		// descriptors already resident (HipSIFTDetector::calc_feature): no second H2D pass
+		explicit HipPairWiseMatcher(const HipFeatureSet& fs): feats(fs.feats), handle(fs.handle), owns(false) {}
+		HipPairWiseMatcher(const HipPairWiseMatcher&) = delete;
+		HipPairWiseMatcher& operator=(const HipPairWiseMatcher&) = delete;
+		~HipPairWiseMatcher() { if (owns) op_features_free(handle); }
+
+		// return pair of <idx in i, idx in j>
+		MatchData match(int i, int j) const {
+			std::lock_guard<std::mutex> lk(mu);
+			if (cache.empty()) precompute_default();
+			auto it = cache.find(std::make_pair(i, j));
+			if (it == cache.end()) {
+				run({{i, j}});
+				it = cache.find(std::make_pair(i, j));
+			}
+			return it->second;
+		}
+
+		// match an explicit task list in one call (Stitcher::pairwise_match's `tasks`)
+		void precompute(const std::vector<std::pair<int, int>>& tasks) const {
+			std::lock_guard<std::mutex> lk(mu);
+			run(tasks);
+		}
+		op_features* device_features() const { return handle; }
+
+	protected:
+		const std::vector<std::vector<Descriptor>>& feats;    // must outlive the matcher (matcher.hh:59)
+		op_features* handle = nullptr;
+		bool owns = true;
+		mutable std::mutex mu;
+		mutable std::map<std::pair<int, int>, MatchData> cache;
+
+		void upload() {
+			const int n = (int)feats.size();
+			std::vector<std::vector<float>> flat(n);
+			std::vector<std::vector<double>> coor(n);
+			std::vector<const float*> dp(n); std::vector<const double*> cp(n); std::vector<int> counts(n);
+			for (int k = 0; k < n; ++k) {       // PairWiseMatcher::build flattening (matcher.cc:75-81)
+				counts[k] = (int)feats[k].size();
+				flat[k].resize((size_t)counts[k] * 128 + 1); coor[k].resize((size_t)counts[k] * 2 + 1);
+				for (int i = 0; i < counts[k]; ++i) {
+					if (feats[k][i].descriptor.size() != 128) { fprintf(stderr, "PairWiseMatcher: descriptors must be 128-D\n"); exit(1); }
+					memcpy(&flat[k][(size_t)i * 128], feats[k][i].descriptor.data(), 128 * sizeof(float));
+					coor[k][2 * i] = feats[k][i].coor.x; coor[k][2 * i + 1] = feats[k][i].coor.y;
+				}
+				dp[k] = flat[k].data(); cp[k] = coor[k].data();
+			}
+			PANO_HIP_CHECK(op_features_from_host(HipContext::get(), dp.data(), cp.data(), counts.data(), n, &handle));
+		}
+		void precompute_default() const {
+			const int n = (int)feats.size();
+			std::vector<std::pair<int, int>> tasks;
+			if (config::ORDERED_INPUT) for (int i = 0; i < n; ++i) tasks.emplace_back(i, (i + 1) % n);   // stitcher.cc:121-124
+			else for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) tasks.emplace_back(i, j);    // stitcher.cc:99-100
+			run(tasks);
+		}
+		void run(const std::vector<std::pair<int, int>>& tasks) const {
+			if (tasks.empty()) return;
+			std::vector<int> pr;
+			for (auto& t : tasks) { pr.push_back(t.first); pr.push_back(t.second); }
+			const op_config cfg = hip_config_snapshot();
+			op_matches* m = nullptr;
+			PANO_HIP_CHECK(op_match_pairs(HipContext::get(), &cfg, handle, pr.data(), (int)tasks.size(), &m));
+			for (size_t p = 0; p < tasks.size(); ++p) {
+				const int c = op_matches_count(m, (int)p);
+				std::vector<int> idx((size_t)c * 2 + 2);
+				if (c) PANO_HIP_CHECK(op_matches_copy(m, (int)p, idx.data()));
+				MatchData md;
+				for (int q = 0; q < c; ++q) md.data.emplace_back(idx[2 * q], idx[2 * q + 1]);
+				cache[tasks[p]] = std::move(md);
+			}
+			op_matches_free(m);
+		}
+};
+
+// ===================================== RANSAC =====================================
+// Same constructor and get_transform as the reference's TransformEstimation
+// (stitch/transform_estimate.hh:22-31).  The reference seeds std::mt19937 from
+// std::random_device per call (transform_estimate.cc:64-65); so does this adapter unless a seed
+// is injected (tests, reproducible runs).
+class HipTransformEstimation {
+	public:
+		HipTransformEstimation(const MatchData& m_match, const std::vector<Vec2D>& kp1, const std::vector<Vec2D>& kp2,
+				const Shape2D& shape1, const Shape2D& shape2):
+			match(m_match), kp1(kp1), kp2(kp2), shape1(shape1), shape2(shape2) {}
+		HipTransformEstimation(const HipTransformEstimation&) = delete;
+		HipTransformEstimation& operator=(const HipTransformEstimation&) = delete;
+
+		static bool& seed_injected() { static bool b = false; return b; }
+		static uint32_t& injected_seed() { static uint32_t s = 0; return s; }
+
+		// get a transform matrix from second(f2) -> first(f1)
+		bool get_transform(MatchInfo* info) {
+			op_ctx* ctx = HipContext::get();
+			const op_config cfg = hip_config_snapshot();
+			std::vector<double> c1(kp1.size() * 2 + 2), c2(kp2.size() * 2 + 2);
+			for (size_t i = 0; i < kp1.size(); ++i) { c1[2 * i] = kp1[i].x; c1[2 * i + 1] = kp1[i].y; }
+			for (size_t i = 0; i < kp2.size(); ++i) { c2[2 * i] = kp2[i].x; c2[2 * i + 1] = kp2[i].y; }
+			const double* cp[2] = {c1.data(), c2.data()};
+			const int counts[2] = {(int)kp1.size(), (int)kp2.size()};
+			op_features* f = nullptr;
+			PANO_HIP_CHECK(op_features_from_host(ctx, nullptr, cp, counts, 2, &f));
+			std::vector<int> idx(match.data.size() * 2 + 2);
+			for (size_t i = 0; i < match.data.size(); ++i) { idx[2 * i] = match.data[i].first; idx[2 * i + 1] = match.data[i].second; }
+			const int* ip[1] = {idx.data()};
+			const int mc[1] = {(int)match.data.size()};
+			op_matches* m = nullptr;
+			PANO_HIP_CHECK(op_matches_from_host(ip, mc, 1, &m));
+			const int pairs[2] = {0, 1};
+			const int shapes[4] = {shape1.w, shape1.h, shape2.w, shape2.h};
+			uint32_t seed = seed_injected() ? injected_seed() : std::random_device{}();
+			op_ransac_result* r = nullptr;
+			PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, f, m, pairs, 1, shapes, &seed, 0, &r));
+			const bool ok = fill(r, 0, match, kp1, kp2, info);
+			op_ransac_free(r); op_matches_free(m); op_features_free(f);
+			return ok;
+		}
+
+		// MatchInfo of pair p of a batched result (fill_inliers_to_matchinfo's outputs,
+		// transform_estimate.cc:150-218)
+		static bool fill(const op_ransac_result* r, int p, const MatchData& match, const std::vector<Vec2D>& kp1,
+				const std::vector<Vec2D>& kp2, MatchInfo* info) {
+			info->confidence = op_ransac_confidence(r, p);
+			if (!op_ransac_ok(r, p)) return false;
+			double h[9];
+			PANO_HIP_CHECK(op_ransac_homo(r, p, h));
+			for (int i = 0; i < 9; ++i) info->homo[i] = h[i];
+			const int n = op_ransac_inlier_count(r, p);
+			std::vector<int> inl(n + 1);
+			if (n) PANO_HIP_CHECK(op_ransac_inliers(r, p, inl.data()));
+			info->match.clear();
+			for (int i = 0; i < n; ++i)
+				info->match.emplace_back(kp1[match.data[inl[i]].first], kp2[match.data[inl[i]].second]);
+			return true;
+		}
+
+	private:
+		const MatchData& match;
+		const std::vector<Vec2D>&kp1, &kp2;
+		const Shape2D shape1, shape2;
+};
+
+// Body of Stitcher::pairwise_match / linear_pairwise_match + match_image (stitch/stitcher.cc:66-136)
+// for a whole task list: ONE matcher call and ONE batched RANSAC call.  out[k] = (succ, info of
+// tasks[k], homography from j to i) -- the caller keeps the reference's bookkeeping
+// (pairwise_matches[i][j] / inverse for [j][i], stitcher.cc:79-93).
+inline std::vector<std::pair<bool, MatchInfo>> hip_match_images(const HipFeatureSet& fs,
+		const std::vector<Shape2D>& shapes, const std::vector<std::pair<int, int>>& tasks, uint32_t base_seed) {
+	op_ctx* ctx = HipContext::get();
+	const op_config cfg = hip_config_snapshot();
+	std::vector<int> pr, sh;
+	for (auto& t : tasks) { pr.push_back(t.first); pr.push_back(t.second); }
+	for (auto& s : shapes) { sh.push_back(s.w); sh.push_back(s.h); }
+	op_matches* m = nullptr;
+	PANO_HIP_CHECK(op_match_pairs(ctx, &cfg, fs.handle, pr.data(), (int)tasks.size(), &m));
+	op_ransac_result* r = nullptr;
+	PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), nullptr, base_seed, &r));
+	std::vector<std::pair<bool, MatchInfo>> out(tasks.size());
+	for (size_t p = 0; p < tasks.size(); ++p) {
+		const int c = op_matches_count(m, (int)p);
+		std::vector<int> idx((size_t)c * 2 + 2);
+		if (c) PANO_HIP_CHECK(op_matches_copy(m, (int)p, idx.data()));
+		MatchData md;
+		for (int q = 0; q < c; ++q) md.data.emplace_back(idx[2 * q], idx[2 * q + 1]);
+		std::vector<Vec2D> k1, k2;
+		for (auto& d : fs.feats[tasks[p].first]) k1.push_back(d.coor);
+		for (auto& d : fs.feats[tasks[p].second]) k2.push_back(d.coor);
+		out[p].first = HipTransformEstimation::fill(r, (int)p, md, k1, k2, &out[p].second);
+	}
+	op_ransac_free(r); op_matches_free(m);
+	return out;
+}
+
+// ===================================== WARP + BLEND =====================================
+#ifndef OPENPANO_WITH_REFERENCE
+// stitch/stitcher_image.hh:15-98 (fields and method names as in the reference)
+struct ConnectedImages {
+	ConnectedImages() = default;
+	ConnectedImages(const ConnectedImages&) = delete;
+	ConnectedImages& operator=(const ConnectedImages&) = delete;
+	struct Range {
+		Vec2D min, max;
+		Range() {}
+		Range(const Vec2D& a, const Vec2D& b): min(a), max(b) {}
+		Vec2D size() const { return max - min; }
+	};
+	enum ProjectionMethod { flat, cylindrical, spherical };
+	ProjectionMethod proj_method = flat;
+	Range proj_range;
+	int identity_idx = 0;
+	struct ImageComponent {
+		Homography homo, homo_inv;
+		ImageRef* imgptr = nullptr;
+		Range range;
+		ImageComponent() {}
+		ImageComponent(ImageRef* img): imgptr(img) {}
+	};
+	std::vector<ImageComponent> component;
+	void calc_inverse_homo() { prepare(); }
+	void update_proj_range() { prepare(); }
+	Vec2D get_final_resolution() const { return resolution; }
+	Mat32f blend() const;
+	Vec2D resolution;
+	private:
+	void prepare();       // calc_inverse_homo + update_proj_range + get_final_resolution in one host call
+};
+#endif
+
+// Geometry of a bundle through the C-ABI's host helper; fills homo_inv / range / proj_range the
+// way ConnectedImages::calc_inverse_homo / update_proj_range do (stitcher_image.cc:36-77)
+template <typename Bundle>
+inline op_blend_geom hip_blend_prepare(const Bundle& b, std::vector<double>& hinv, std::vector<double>& ranges) {
+	const int n = (int)b.component.size();
+	std::vector<double> homo((size_t)n * 9); std::vector<int> shapes((size_t)n * 2);
+	for (int i = 0; i < n; ++i) {
+		for (int k = 0; k < 9; ++k) homo[(size_t)i * 9 + k] = b.component[i].homo[k];
+		shapes[2 * i] = b.component[i].imgptr->width(); shapes[2 * i + 1] = b.component[i].imgptr->height();
+	}
+	hinv.assign((size_t)n * 9, 0); ranges.assign((size_t)n * 4, 0);
+	op_blend_geom g;
+	const op_config cfg = hip_config_snapshot();
+	PANO_HIP_CHECK(op_blend_prepare(&cfg, (int)b.proj_method, b.identity_idx, n, shapes.data(), homo.data(), &g, hinv.data(), ranges.data()));
+	return g;
+}
+
+// ConnectedImages::blend() (stitch/stitcher_image.cc:116-155) on the device.  Uses the bundle's
+// own homo_inv / range / proj_range (already filled by calc_inverse_homo / update_proj_range)
+// and the resolution of get_final_resolution(); the blender is chosen like the reference does
+// (config::MULTIBAND > 0 ? MultiBandBlender : LinearBlender).
+template <typename Bundle>
+inline Mat32f hip_blend(const Bundle& b) {
+	op_ctx* ctx = HipContext::get();
+	const op_config cfg = hip_config_snapshot();
+	const int n = (int)b.component.size();
+	const Vec2D res = b.get_final_resolution();
+	op_blend_geom g;
+	g.proj_method = (int)b.proj_method;
+	g.proj_min[0] = b.proj_range.min.x; g.proj_min[1] = b.proj_range.min.y;
+	g.proj_max[0] = b.proj_range.max.x; g.proj_max[1] = b.proj_range.max.y;
+	g.resolution[0] = res.x; g.resolution[1] = res.y;
+	std::vector<op_blend_image> ims(n);
+	for (int i = 0; i < n; ++i) {
+		auto& c = b.component[i];
+		c.imgptr->load();
+		ims[i].data = c.imgptr->img->ptr(); ims[i].h = c.imgptr->height(); ims[i].w = c.imgptr->width(); ims[i].on_device = 0;
+		for (int k = 0; k < 9; ++k) ims[i].homo_inv[k] = c.homo_inv[k];
+		ims[i].range[0] = c.range.min.x; ims[i].range[1] = c.range.min.y; ims[i].range[2] = c.range.max.x; ims[i].range[3] = c.range.max.y;
+	}
+	op_canvas* cv = nullptr;
+	PANO_HIP_CHECK(op_blend(ctx, &cfg, &g, ims.data(), n, &cv));
+	int h, w;
+	PANO_HIP_CHECK(op_canvas_dims(cv, &h, &w));
+	Mat32f out(h, w, 3);
+	PANO_HIP_CHECK(op_canvas_copy(ctx, cv, out.ptr()));
+	op_canvas_free(cv);
+	return out;
+}
+
+#ifndef OPENPANO_WITH_REFERENCE
+inline void ConnectedImages::prepare() {
+	std::vector<double> hinv, ranges;
+	const op_blend_geom g = hip_blend_prepare(*this, hinv, ranges);
+	for (size_t i = 0; i < component.size(); ++i) {
+		for (int k = 0; k < 9; ++k) component[i].homo_inv[k] = hinv[i * 9 + k];
+		component[i].range = Range(Vec2D(ranges[4 * i], ranges[4 * i + 1]), Vec2D(ranges[4 * i + 2], ranges[4 * i + 3]));
+	}
+	proj_range = Range(Vec2D(g.proj_min[0], g.proj_min[1]), Vec2D(g.proj_max[0], g.proj_max[1]));
+	resolution = Vec2D(g.resolution[0], g.resolution[1]);
+}
+inline Mat32f ConnectedImages::blend() const { return hip_blend(*this); }
+#endif
+
+// CylinderWarper (stitch/warp.hh:42-61): same method set
+class HipCylinderWarper {
+	public:
+		explicit HipCylinderWarper(double m_hfactor): h_factor(m_hfactor) {}
+		// warp image together with key points
+		void warp(Mat32f& mat, std::vector<Vec2D>& kpts) const {
+			op_ctx* ctx = HipContext::get();
+			const op_config cfg = hip_config_snapshot();
+			Shape2D shape(mat.width(), mat.height());
+			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0};
+			op_canvas* cv = nullptr;
+			PANO_HIP_CHECK(op_cyl_warp(ctx, &cfg, &im, h_factor, &cv));
+			warp(shape, kpts);
+			int h, w;
+			PANO_HIP_CHECK(op_canvas_dims(cv, &h, &w));
+			Mat32f out(h, w, 3);
+			PANO_HIP_CHECK(op_canvas_copy(ctx, cv, out.ptr()));
+			op_canvas_free(cv);
+			mat = out;
+		}
+		// warp keypoints given image shape
+		void warp(Shape2D& shape, std::vector<Vec2D>& kpts) const {
+			const op_config cfg = hip_config_snapshot();
+			std::vector<double> p(kpts.size() * 2 + 2);
+			for (size_t i = 0; i < kpts.size(); ++i) { p[2 * i] = kpts[i].x; p[2 * i + 1] = kpts[i].y; }
+			int nw, nh; double off[2];
+			PANO_HIP_CHECK(op_cyl_warp_shape(&cfg, shape.w, shape.h, h_factor, kpts.empty() ? nullptr : p.data(), (int)kpts.size(), &nw, &nh, off));
+			for (size_t i = 0; i < kpts.size(); ++i) kpts[i] = Vec2D(p[2 * i], p[2 * i + 1]);
+			shape.w = nw; shape.h = nh;
+		}
+		// warp image only
+		void warp(Mat32f& mat) const { std::vector<Vec2D> a; warp(mat, a); }
+	protected:
+		const double h_factor;
+};
+
+#ifndef OPENPANO_WITH_REFERENCE
+// standalone builds read like the reference
+using SIFTDetector = HipSIFTDetector;
+using PairWiseMatcher = HipPairWiseMatcher;
+using TransformEstimation = HipTransformEstimation;
+using CylinderWarper = HipCylinderWarper;
+#endif
+
+}	// namespace pano

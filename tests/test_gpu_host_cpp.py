@@ -1,0 +1,100 @@
+"""GPU: the C++ host layer above the C-ABI.
+
+test_stitch_demo   -- openpano_amd/host/stitch_demo (standalone C++ program written with the
+                      reference's class names over pano_hip.hh; no Python in the product path):
+                      every section of its output is checked against the CPU oracle.
+test_reference_dropin -- oracle/_ref/ref_dropin_test: the adapters compiled against the
+                      reference's OWN headers and linked with the reference's own classes; built in
+                      the container that has /root/reference, travels as a binary.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from openpano_amd import synth
+from openpano_amd.config import PanoConfig
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "openpano_amd", "host", "stitch_demo")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_test")
+
+
+def _env():
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    return env
+
+
+class _Reader:
+    def __init__(self, buf):
+        self.b = buf; self.o = 0
+
+    def take(self, dtype, n):
+        a = np.frombuffer(self.b, dtype=dtype, count=n, offset=self.o).copy()
+        self.o += a.nbytes
+        return a
+
+
+def test_stitch_demo(tmp_path, oracle):
+    assert os.path.exists(DEMO), "build it: make -C openpano_amd/csrc"
+    n, h, w = 4, 240, 320
+    views = synth.image_set(n, h, w, seed=5, overlap=0.5)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", n, h, w))
+        for v in views:
+            f.write(np.ascontiguousarray(v, np.float32).tobytes())
+    base_seed = 42
+    r = subprocess.run([DEMO, str(fin), str(fout), str(base_seed)], capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rd = _Reader(open(fout, "rb").read())
+    cfg = PanoConfig(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1, LAZY_READ=0)
+    from checkers import Oracle
+    orc = Oracle(cfg)
+    descs, coors = [], []
+    for k in range(n):
+        K = int(rd.take(np.int32, 1)[0])
+        d = rd.take(np.float32, K * 128).reshape(K, 128); c = rd.take(np.float64, K * 2).reshape(K, 2)
+        od, oc = orc.detect_feature(views[k])
+        assert K > 100 and np.array_equal(d, od) and np.array_equal(c, oc), f"image {k}"
+        descs.append(d); coors.append(c)
+    npairs = int(rd.take(np.int32, 1)[0])
+    assert npairs == n - 1
+    connected = 0
+    for p in range(npairs):
+        i, j, M = (int(x) for x in rd.take(np.int32, 3))
+        m = rd.take(np.int32, M * 2).reshape(M, 2)
+        want = orc.match_exact(descs[i], descs[j])
+        assert np.array_equal(m, want), f"pair {p}"
+        ok = int(rd.take(np.int32, 1)[0]); conf = float(rd.take(np.float32, 1)[0])
+        homo = rd.take(np.float64, 9).reshape(3, 3); ninl = int(rd.take(np.int32, 1)[0])
+        pts = rd.take(np.float64, ninl * 4).reshape(ninl, 4)
+        seed = ((base_seed * 2654435761) ^ (p * 40503 + 12345)) & 0xFFFFFFFF
+        o = orc.ransac(m, coors[i], coors[j], (w, h), (w, h), seed, cfg)
+        assert bool(ok) == o["ok"] and conf == np.float32(o["confidence"]), f"pair {p}"
+        if ok:
+            connected += 1
+            inl = o["inliers"]
+            assert ninl == len(inl)
+            assert np.array_equal(pts[:, :2], coors[i][m[inl, 0]]) and np.array_equal(pts[:, 2:], coors[j][m[inl, 1]])
+            assert np.allclose(homo, o["homo"], rtol=1e-9, atol=1e-12)
+    assert connected == npairs, "synthetic neighbours must connect"
+    H, W = (int(x) for x in rd.take(np.int32, 2))
+    assert H > 200 and W > 600
+    pano = rd.take(np.float32, H * W * 3).reshape(H, W, 3)
+    to_mid = rd.take(np.float64, n * 9).reshape(n, 3, 3)
+    want, _ = orc.blend(views, to_mid, 0, n >> 1, cfg)
+    assert want.shape == pano.shape
+    assert np.array_equal(pano, want)          # flat projection: no transcendental -> bit-exact
+
+
+def test_reference_dropin():
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/ref_dropin_test not built (reference sources absent at build time)")
+    r = subprocess.run([DROPIN], capture_output=True, text=True, env=_env(), timeout=600, cwd=os.path.dirname(DROPIN))
+    print(r.stdout[-4000:])
+    assert r.returncode == 0 and "DROPIN OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
