@@ -21,8 +21,8 @@
 
 namespace {
 
-constexpr int REC_CAP = 512;         // records (surviving samples) buffered per flush
-constexpr int LIST_CAP = 256;        // entries per spatial-cell list per flush
+constexpr int REC_CAP = 256;         // records (surviving samples) buffered per flush
+constexpr int LIST_CAP = 128;        // entries per spatial-cell list per flush
 
 struct DescLds {
 	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
