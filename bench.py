@@ -159,8 +159,9 @@ def main():
     dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
     # algorithmic HBM bytes per launch (DESIGN.md "kernels"), per image:
     alg = {
-        "build pyramid": 4 * P + 24 * P + 32 * P,                        # grey in, 6 DoG + 4 mag + 4 ort out
-        "extrema scan": 24 * P,                                          # the 6 DoG planes once
+        # fused scale space + extrema scan: grey in; 6 DoG + 4 Gaussian planes out (DESIGN.md section 3;
+        # the scan runs on the DoG layers while they are in LDS and mag/ort are never materialised)
+        "build pyramid": 4 * P + 24 * P + 16 * P,
         "resize": 12 * H * W + 12 * wh * ww,
         "octave grey": 12 * wh * ww + 4 * P,
         "sift descriptor": (k_rank / nimg) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output

@@ -49,8 +49,9 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		const OctDesc od = p.oct[kp.oct];
 		const int w = od.w, h = od.h;
 		const float* base = p.ws + (long long)img * p.ws_stride;
-		const float* mag_img = base + plane_off_mag(od, p.nscale, kp.scale);
-		const float* ort_img = base + plane_off_ort(od, p.nscale, kp.scale);
+		// mag / ort of GaussianPyramid::cal_mag_ort (feature/dog.cc:76-84) are evaluated on the
+		// Gaussian plane for the surviving window samples only
+		const float* g_img = base + plane_off_gauss(od, p.nscale, kp.scale);
 		const float ort = kp.dir;
 		const float hist_w = kp.sf * (float)p.desc_scale_factor;
 		const float exp_denom = 2 * (4.f * 4.f);
@@ -126,8 +127,10 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			const int ridx = nrec + __popcll(mask & lt_mask);
 			int yb = -9, xb = -9, h0 = 0;
 			if (ok) {
-				const float now_mag = mag_img[gi];
-				float now_ort = ort_img[gi];
+				const float gdy = g_img[gi + w] - g_img[gi - w];
+				const float gdx = g_img[gi + 1] - g_img[gi - 1];
+				const float now_mag = opdev::hypotf_glibc(gdx, gdy);
+				float now_ort = opdev::fast_atan_plus_pi(gdy, gdx);
 				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom);
 				weight = weight * now_mag;
 				now_ort -= ort;

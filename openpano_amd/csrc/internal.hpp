@@ -45,9 +45,12 @@ void resolve_profile(op_ctx* c);
 
 // ---------------------------------------------------------------------------------------
 // HBM layout of one image's scale space ("image workspace", ws_stride floats per image):
-//   for each octave o:  [grey][DoG 0 .. ns-2][mag 1 .. ns-3][ort 1 .. ns-3]   each h_o*w_o fp32,
-// row-major, octave blocks back to back.  The six Gaussian planes of the reference
-// (feature/dog.cc:53-57) never touch HBM: they live in LDS inside the pyramid kernel.
+//   for each octave o:  [grey][DoG 0 .. ns-2][gauss 1 .. ns-3]   each h_o*w_o fp32, row-major,
+// octave blocks back to back.  Of the reference's Gaussian stack (feature/dog.cc:53-57) only the
+// planes whose gradients are ever read (scale_id in [1, ns-3]: extrema.cc:75, orientation.cc:37,
+// sift.cc:96) reach HBM; the mag/ort planes of GaussianPyramid::cal_mag_ort (dog.cc:60-94) are
+// never materialised -- the orientation and descriptor kernels evaluate the same expressions on
+// the Gaussian plane for exactly the window samples they use.
 // ---------------------------------------------------------------------------------------
 struct OctDesc {
 	int h, w;
@@ -80,9 +83,8 @@ struct SiftPlan {
 
 __host__ __device__ inline long long plane_off_grey(const OctDesc& o) { return o.off; }
 __host__ __device__ inline long long plane_off_dog(const OctDesc& o, int s) { return o.off + (1 + s) * o.plane; }
-__host__ __device__ inline long long plane_off_mag(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (s - 1)) * o.plane; }
-__host__ __device__ inline long long plane_off_ort(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (ns - 3) + (s - 1)) * o.plane; }
-__host__ __device__ inline int planes_per_octave(int ns) { return 1 + (ns - 1) + 2 * (ns - 3); }
+__host__ __device__ inline long long plane_off_gauss(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (s - 1)) * o.plane; }
+__host__ __device__ inline int planes_per_octave(int ns) { return 1 + (ns - 1) + (ns - 3); }
 
 // a scale-space point (feature/feature.hh:33-39), 48 bytes
 struct KeyPoint {
@@ -94,13 +96,17 @@ struct KeyPoint {
 };
 
 #define OP_PYR_TW 64
-#define OP_PYR_TH 32
+#ifndef OP_PYR_TH
+#define OP_PYR_TH 16
+#endif
 
 // ---- kernel launchers (each returns hipGetLastError of its launch) ----
 hipError_t launch_resize_to_work(const SiftPlan& p, hipStream_t st);
 hipError_t launch_octave_grey(const SiftPlan& p, hipStream_t st);
-hipError_t launch_pyramid(const SiftPlan& p, hipStream_t st);
-hipError_t launch_extrema_scan(const SiftPlan& p, int* raw /* n x cap x 4 */, int* raw_count /* n */, int cap, hipStream_t st);
+// fused scale space + extrema scan: fills the DoG / Gaussian planes and appends raw extrema
+hipError_t launch_pyramid(const SiftPlan& p, int* raw /* n x cap x 4 */, int* raw_count /* n */, int cap, hipStream_t st);
+// debug/staged dump only: mag and ort of one Gaussian plane (GaussianPyramid::cal_mag_ort)
+hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float* mag, float* ort, hipStream_t st);
 hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap,
 		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
 hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,

@@ -13,82 +13,6 @@ __device__ __forceinline__ const float* dog_plane(const SiftPlan& p, int img, in
 	return p.ws + (long long)img * p.ws_stride + plane_off_dog(p.oct[o], s);
 }
 
-// ---- extrema scan (feature/extrema.cc:170-216) ----
-// Each thread owns SCAN_PPT pixels (coalesced across the wave) and first issues the centre loads
-// of all scanned layers for all of them -- SCAN_PPT x (nscale-3) independent loads in flight per
-// lane, so the pass streams the DoG planes at HBM rate instead of waiting out one load latency
-// per layer.  Only centres above PRE_COLOR_THRES (:179, a few percent) run the 26-neighbour test.
-constexpr int SCAN_PPT = 4;
-constexpr int SCAN_MAXL = OP_MAX_SCALE - 3;
-
-__device__ __forceinline__ void extrema_test(const SiftPlan& p, int img, int o, int s, const OctDesc& od,
-		long long idx, float center, int* raw, int* raw_count, int cap) {
-	const int w = od.w;
-	const float* now = dog_plane(p, img, o, s);
-	bool mx = true, mn = true;
-	const float cmp1 = center - p.judge_thres, cmp2 = center + p.judge_thres;
-#pragma unroll
-	for (int di = -1; di <= 1; ++di)
-#pragma unroll
-		for (int dj = -1; dj <= 1; ++dj) {
-			if (di == 0 && dj == 0) continue;
-			const float v = now[idx + di * w + dj];
-			if (v >= cmp1) mx = false;
-			if (v <= cmp2) mn = false;
-		}
-	if (!mx && !mn) return;
-	for (int ds = -1; ds <= 1; ds += 2) {
-		const float* mat = dog_plane(p, img, o, s + ds);
-#pragma unroll
-		for (int di = -1; di <= 1; ++di)
-#pragma unroll
-			for (int dj = -1; dj <= 1; ++dj) {
-				const float v = mat[idx + di * w + dj];
-				if (v >= cmp1) mx = false;
-				if (v <= cmp2) mn = false;
-			}
-	}
-	if (!mx && !mn) return;
-	const int slot = atomicAdd(&raw_count[img], 1);
-	if (slot < cap) {
-		int* q = raw + ((long long)img * cap + slot) * 4;
-		q[0] = (int)(idx % w); q[1] = (int)(idx / w); q[2] = o; q[3] = s;
-	}
-}
-
-__global__ void __launch_bounds__(256) k_extrema_scan(SiftPlan p, int* raw, int* raw_count, int cap) {
-	const int img = blockIdx.z, o = blockIdx.y;
-	const OctDesc od = p.oct[o];
-	const long long base = (long long)blockIdx.x * (256 * SCAN_PPT) + threadIdx.x;
-	if (base - threadIdx.x >= od.plane) return;
-	const int nl = p.nscale - 3;                                      // layers 1 .. nscale-3 (extrema.cc:42)
-	const float* d1 = dog_plane(p, img, o, 1);
-	float c[SCAN_PPT][SCAN_MAXL];
-	bool live[SCAN_PPT];
-#pragma unroll
-	for (int k = 0; k < SCAN_PPT; ++k) {
-		const long long idx = base + 256 * k;
-		bool ok = idx < od.plane;
-		if (ok) {
-			const int r = (int)(idx / od.w), cc = (int)(idx % od.w);
-			ok = r >= 1 && r <= od.h - 2 && cc >= 1 && cc <= od.w - 2;   // :212
-		}
-		live[k] = ok;
-#pragma unroll
-		for (int l = 0; l < SCAN_MAXL; ++l)
-			c[k][l] = (ok && l < nl) ? d1[(long long)l * od.plane + idx] : -1.f;
-	}
-#pragma unroll
-	for (int k = 0; k < SCAN_PPT; ++k) {
-		if (!live[k]) continue;
-#pragma unroll
-		for (int l = 0; l < SCAN_MAXL; ++l) {
-			if (l >= nl || c[k][l] < p.pre_color_thres) continue;    // :179
-			extrema_test(p, img, o, l + 1, od, base + 256 * k, c[k][l], raw, raw_count, cap);
-		}
-	}
-}
-
 // Eigen::FullPivLU 3x3 inverse as used by Matrix::inverse (lib/matrix.cc:76-87): complete
 // pivoting, rank threshold |pivot| > |maxpivot| * eps * 3, inverse = solve(Identity).
 __device__ bool inverse3_fullpiv(const double a[9], double inv[9]) {
@@ -323,8 +247,9 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 	for (int k = blockIdx.x; k < count; k += gridDim.x) {
 		const KeyPoint kp = refined[(long long)img * cap + k];
 		const OctDesc od = p.oct[kp.oct];
-		const float* mag_img = base + plane_off_mag(od, p.nscale, kp.scale);
-		const float* ort_img = base + plane_off_ort(od, p.nscale, kp.scale);
+		// gradient magnitude / orientation of GaussianPyramid::cal_mag_ort (feature/dog.cc:76-84),
+		// evaluated on the Gaussian plane for the window samples only
+		const float* g_img = base + plane_off_gauss(od, p.nscale, kp.scale);
 		const float gauss_weight_sigma = kp.sf * 1.5f;                 // ORI_WINDOW_FACTOR
 		const int rad = (int)roundf(kp.sf * p.ori_radius);
 		const float exp_denom = 2 * (gauss_weight_sigma * gauss_weight_sigma);
@@ -343,11 +268,13 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 					const float r2 = fxx * fxx + fyy * fyy;
 					if (!(r2 > frad2)) {
 						const long long gi = (long long)newy * od.w + newx;
-						const float orient = ort_img[gi];
+						const float gdy = g_img[gi + od.w] - g_img[gi - od.w];
+						const float gdx = g_img[gi + 1] - g_img[gi - 1];
+						const float orient = opdev::fast_atan_plus_pi(gdy, gdx);
 						bin = (int)roundf(36 * halfipi * orient);
 						if (bin == ORI_BINS) bin = 0;
 						const float weight = opdev::expf_glibc(-r2 / exp_denom);
-						val = weight * mag_img[gi];
+						val = weight * opdev::hypotf_glibc(gdx, gdy);
 					}
 				}
 				s_bin[i] = (signed char)bin; s_val[i] = val;
@@ -447,13 +374,6 @@ __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined
 }
 
 }	// namespace
-
-hipError_t launch_extrema_scan(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
-	const int per_block = 256 * SCAN_PPT;
-	dim3 grid((unsigned)((p.oct[0].plane + per_block - 1) / per_block), p.noct, p.n);
-	hipLaunchKernelGGL(k_extrema_scan, grid, dim3(256), 0, st, p, raw, raw_count, cap);
-	return hipGetLastError();
-}
 
 hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap,
 		KeyPoint* refined, int* refined_count, hipStream_t st) {

@@ -89,7 +89,14 @@ __global__ void __launch_bounds__(256) k_octave_grey(SiftPlan p) {
 constexpr int TW = OP_PYR_TW, TH = OP_PYR_TH;
 constexpr int GR = TH + 2, GC = TW + 2;       // blurred region incl. the 1-px gradient halo
 constexpr int PG = GC + 1;                    // pitch of G buffers (odd: lanes along rows are conflict-free)
-constexpr int PV = GR + 1;                    // pitch of the transposed column-pass buffer
+constexpr int PV = GR + (GR % 2 == 0 ? 1 : 2);  // pitch of the transposed column-pass buffer (odd -> conflict-free)
+constexpr int NPX = TW * TH / 256;            // tile pixels owned by one thread (lx = tid & 63, ly = (tid >> 6) + 4 k)
+constexpr int NHALO = 2 * GC + 2 * TH;        // ring elements of the G / DoG region around the tile
+static_assert(TW == 64 && TH % 4 == 0 && NHALO <= 256, "tile shape");
+// register blocking of the separable passes: strips of RV rows (column pass) / RH columns (row pass)
+constexpr int RV = TH == 32 ? 12 : (TH == 24 ? 9 : 6);
+constexpr int RH = TH == 32 ? 10 : (TH == 24 ? 8 : 5);
+static_assert(((GR + RV - 1) / RV) * (GC + 12) <= 256 && ((GC + RH - 1) / RH) * GR <= 256, "blocking must fit 256 threads at halo 6");
 
 // register-blocked passes for kernel half-width C (taps = 2C+1)
 template <int C, int RV>
@@ -165,7 +172,43 @@ __device__ __forceinline__ void hpass_generic(const float* VT, float* G, const f
 	}
 }
 
-__global__ void __launch_bounds__(256) k_pyramid(SiftPlan p) {
+// Raw-extrema test of one tile pixel against the three DoG layers held in LDS
+// (ExtremaDetector::get_local_raw_extrema, feature/extrema.cc:170-216)
+__device__ __forceinline__ bool is_raw_extremum(const float* __restrict__ Dm, const float* __restrict__ D0,
+		const float* __restrict__ Dp, int gy, int gx, float center, float judge) {
+	bool mx = true, mn = true;
+	const float cmp1 = center - judge, cmp2 = center + judge;
+#pragma unroll
+	for (int di = -1; di <= 1; ++di)
+#pragma unroll
+		for (int dj = -1; dj <= 1; ++dj) {
+			if (di == 0 && dj == 0) continue;
+			const float v = D0[(gy + di) * PG + gx + dj];
+			if (v >= cmp1) mx = false;
+			if (v <= cmp2) mn = false;
+		}
+	if (!mx && !mn) return false;
+#pragma unroll
+	for (int di = -1; di <= 1; ++di)
+#pragma unroll
+		for (int dj = -1; dj <= 1; ++dj) {
+			const float v = Dm[(gy + di) * PG + gx + dj], u = Dp[(gy + di) * PG + gx + dj];
+			if (v >= cmp1 || u >= cmp1) mx = false;
+			if (v <= cmp2 || u <= cmp2) mn = false;
+		}
+	return mx || mn;
+}
+
+// K3: fused scale space + extrema scan.  One 256-thread workgroup owns a TW x TH tile of one
+// octave and walks the sigmas.  Per sigma: separable blur of the *unblurred* grey tile (column
+// pass, then row pass, replicate borders -- feature/gaussian.hh:43-89) through LDS with
+// register-blocked sliding windows.  Then every thread handles its NPX fixed tile pixels (lanes
+// along x: coalesced HBM rows) plus one element of the 1-px ring: |DoG| against the previous
+// Gaussian value it kept in registers (feature/dog.cc:126) goes into a 3-deep LDS ring of DoG
+// layers and to HBM (the sub-pixel refinement reads it), the Gaussian value goes to HBM when its
+// gradients will be needed.  As soon as three consecutive DoG layers sit in LDS the middle one is
+// scanned for raw extrema (feature/extrema.cc:170-216) -- nothing is re-read from HBM.
+__global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int img = blockIdx.y;
 	const int tile = blockIdx.x;
@@ -179,8 +222,8 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p) {
 	const int NR = GR + 2 * halo, NC = GC + 2 * halo, pin = NC;
 	float* In = smem;                       // NR x NC
 	float* VT = In + NR * pin;              // NC x PV (column-pass result, transposed)
-	float* Ga = VT + NC * PV;               // GR x PG
-	float* Gb = Ga + GR * PG;
+	float* G = VT + NC * PV;                // GR x PG current Gaussian
+	float* Dr = G + GR * PG;                // 3 x GR x PG ring of DoG layers
 	const int tid = threadIdx.x;
 	const int ns = p.nscale;
 	float* ws = p.ws + (long long)img * p.ws_stride;
@@ -195,53 +238,109 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p) {
 		xx = xx < 0 ? 0 : (xx > od.w - 1 ? od.w - 1 : xx);
 		In[r * pin + c] = grey[(long long)yy * od.w + xx];
 	}
+
+	// this thread's fixed pixels
+	const int lx = tid & 63, ly0 = tid >> 6;
+	const int x = x0 + lx;
+	const int lds0 = (ly0 + 1) * PG + lx + 1;                 // LDS offset of pixel k = lds0 + 4 k PG
+	const unsigned gi0 = (unsigned)((y0 + ly0) * od.w + x);     // plane offset of pixel k = gi0 + 4 k w
+	int nvalid = 0;                                             // pixels k < nvalid are inside the image
+	if (x < od.w) { const int rows = od.h - (y0 + ly0); nvalid = rows <= 0 ? 0 : (rows + 3) / 4; nvalid = nvalid > NPX ? NPX : nvalid; }
+	const bool xin = x >= 1 && x <= od.w - 2;                   // extrema.cc:212
+	// one ring element: top row, bottom row, left column, right column of the GR x GC region
+	int hoff = -1;
+	if (tid < GC) hoff = tid;
+	else if (tid < 2 * GC) hoff = (GR - 1) * PG + (tid - GC);
+	else if (tid < 2 * GC + TH) hoff = (1 + tid - 2 * GC) * PG;
+	else if (tid < NHALO) hoff = (1 + tid - 2 * GC - TH) * PG + GC - 1;
 	__syncthreads();
 
-	float* Gcur = Ga;
-	float* Gprev = Gb;
+	float prev[NPX], dprev[NPX], prev_h = 0.f;
+#pragma unroll
+	for (int k = 0; k < NPX; ++k) {
+		prev[k] = In[(ly0 + 4 * k + 1 + halo) * pin + lx + 1 + halo];   // data[0]: the unblurred grey (dog.cc:53)
+		dprev[k] = 0.f;
+	}
+	if (hoff >= 0) prev_h = In[(hoff / PG + halo) * pin + hoff % PG + halo];
+
 	for (int s = 1; s < ns; ++s) {
 		const int C = p.kcenter[s];
 		const float* kern = &p.kern[s][OP_MAX_KCENTER];
-		if (halo == 6 && C == 3) vpass_blocked<3, 12>(In, VT, kern, NC, pin, halo, tid);
-		else if (halo == 6 && C == 6) vpass_blocked<6, 12>(In, VT, kern, NC, pin, halo, tid);
+		if (halo == 6 && C == 3) vpass_blocked<3, RV>(In, VT, kern, NC, pin, halo, tid);
+		else if (halo == 6 && C == 6) vpass_blocked<6, RV>(In, VT, kern, NC, pin, halo, tid);
 		else vpass_generic(In, VT, kern, C, NC, pin, halo, tid);
 		__syncthreads();
-		if (halo == 6 && C == 3) hpass_blocked<3, 10>(VT, Gcur, kern, NC, halo, tid);
-		else if (halo == 6 && C == 6) hpass_blocked<6, 10>(VT, Gcur, kern, NC, halo, tid);
-		else hpass_generic(VT, Gcur, kern, C, halo, tid);
+		if (halo == 6 && C == 3) hpass_blocked<3, RH>(VT, G, kern, NC, halo, tid);
+		else if (halo == 6 && C == 6) hpass_blocked<6, RH>(VT, G, kern, NC, halo, tid);
+		else hpass_generic(VT, G, kern, C, halo, tid);
 		__syncthreads();
 
-		float* dog = ws + plane_off_dog(od, s - 1);
-		const bool want_grad = (s <= ns - 3);
-		float* mag = ws + plane_off_mag(od, ns, want_grad ? s : 1);
-		float* ort = ws + plane_off_ort(od, ns, want_grad ? s : 1);
-#pragma unroll 2
-		for (int e = tid; e < TW * TH; e += 256) {
-			const int ly = e / TW, lx = e % TW;
-			const int y = y0 + ly, x = x0 + lx;
-			if (y >= od.h || x >= od.w) continue;
-			const int gy = ly + 1, gx = lx + 1;
-			const float cur = Gcur[gy * PG + gx];
-			const float prev = (s == 1) ? In[(gy + halo) * pin + gx + halo] : Gprev[gy * PG + gx];
-			const long long gi = (long long)y * od.w + x;
-			dog[gi] = fabsf(prev - cur);                     // feature/dog.cc:126
-			if (want_grad) {
-				float m = 0.f, a = (float)3.14159265358979323846;
-				if (x >= 1 && x <= od.w - 2 && y >= 1 && y <= od.h - 2) {   // feature/dog.cc:76-90
-					const float dy = Gcur[(gy + 1) * PG + gx] - Gcur[(gy - 1) * PG + gx];
-					const float dx = Gcur[gy * PG + gx + 1] - Gcur[gy * PG + gx - 1];
-					m = opdev::hypotf_glibc(dx, dy);
-					a = opdev::fast_atan_plus_pi(dy, dx);
+		const int d = s - 1;                                 // DoG layer produced by this sigma
+		float* Dcur = Dr + (d % 3) * (GR * PG);
+		float* dog = ws + plane_off_dog(od, d);
+		const bool want_gauss = (s <= ns - 3);               // scales whose gradients are read (extrema.cc:75)
+		float* gauss = ws + plane_off_gauss(od, ns, want_gauss ? s : 1);
+		float dcen[NPX];                                     // layer d-1 at this thread's pixels (scan centre)
+#pragma unroll
+		for (int k = 0; k < NPX; ++k) {
+			const float cur = G[lds0 + 4 * k * PG];
+			const float dv = fabsf(prev[k] - cur);           // feature/dog.cc:126
+			Dcur[lds0 + 4 * k * PG] = dv;
+			if (k < nvalid) {
+				const unsigned gi = gi0 + (unsigned)(4 * k) * (unsigned)od.w;
+				dog[gi] = dv;
+				if (want_gauss) gauss[gi] = cur;
+			}
+			prev[k] = cur;
+			dcen[k] = dprev[k]; dprev[k] = dv;
+		}
+		if (hoff >= 0) {
+			const float cur = G[hoff];
+			Dcur[hoff] = fabsf(prev_h - cur);
+			prev_h = cur;
+		}
+		__syncthreads();
+		if (d >= 2 && xin) {                                 // layers d-2, d-1, d in LDS: scan d-1 (extrema.cc:42)
+			const int j = d - 1;
+			const float* D0 = Dr + (j % 3) * (GR * PG);
+			const float* Dm = Dr + ((j + 2) % 3) * (GR * PG);   // layer j-1
+			const float* Dp = Dcur;                              // layer j+1
+#pragma unroll
+			for (int k = 0; k < NPX; ++k) {
+				const int y = y0 + ly0 + 4 * k;
+				if (k >= nvalid || y < 1 || y > od.h - 2) continue;              // extrema.cc:212
+				const float center = dcen[k];
+				if (center < p.pre_color_thres) continue;                          // :179
+				if (!is_raw_extremum(Dm, D0, Dp, ly0 + 4 * k + 1, lx + 1, center, p.judge_thres)) continue;
+				const int slot = atomicAdd(&raw_count[img], 1);
+				if (slot < cap) {
+					int* q = raw + ((long long)img * cap + slot) * 4;
+					q[0] = x; q[1] = y; q[2] = o; q[3] = j;
 				}
-				mag[gi] = m;
-				ort[gi] = a;
 			}
 		}
-		float* tmp = Gprev; Gprev = Gcur; Gcur = tmp;
 		// no barrier needed here: the next column pass only writes VT (its readers are past the
-		// barrier above) and the next row pass writes the buffer that was Gprev only after the
-		// barrier that follows the column pass.
+		// barriers above); the next row pass overwrites G, whose readers (the loop above) are
+		// separated from it by the barrier after the column pass; the next DoG layer overwrites
+		// ring slot (d+1)%3 = layer d-2, last read by this scan, two barriers earlier.
 	}
+}
+
+// debug / staged dump: GaussianPyramid::cal_mag_ort (feature/dog.cc:60-94) of one Gaussian plane
+__global__ void __launch_bounds__(256) k_magort_plane(SiftPlan p, int img, int o, int s, float* mag, float* ort) {
+	const OctDesc od = p.oct[o];
+	const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (idx >= od.plane) return;
+	const int y = (int)(idx / od.w), x = (int)(idx % od.w);
+	const float* g = p.ws + (long long)img * p.ws_stride + plane_off_gauss(od, p.nscale, s);
+	float m = 0.f, a = (float)3.14159265358979323846;
+	if (x >= 1 && x <= od.w - 2 && y >= 1 && y <= od.h - 2) {
+		const float dy = g[idx + od.w] - g[idx - od.w];
+		const float dx = g[idx + 1] - g[idx - 1];
+		m = opdev::hypotf_glibc(dx, dy);
+		a = opdev::fast_atan_plus_pi(dy, dx);
+	}
+	mag[idx] = m; ort[idx] = a;
 }
 
 __global__ void k_debug_math(int which, const float* x, const float* y, int n, float* out) {
@@ -262,7 +361,7 @@ __global__ void k_debug_math(int which, const float* x, const float* y, int n, f
 
 size_t pyramid_lds_bytes(int halo) {
 	const int NR = GR + 2 * halo, NC = GC + 2 * halo;
-	return sizeof(float) * ((size_t)NR * NC + (size_t)NC * PV + 2 * (size_t)GR * PG);
+	return sizeof(float) * ((size_t)NR * NC + (size_t)NC * PV + 4 * (size_t)GR * PG);
 }
 
 hipError_t launch_resize_to_work(const SiftPlan& p, hipStream_t st) {
@@ -277,7 +376,13 @@ hipError_t launch_octave_grey(const SiftPlan& p, hipStream_t st) {
 	return hipGetLastError();
 }
 
-hipError_t launch_pyramid(const SiftPlan& p, hipStream_t st) {
+hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float* mag, float* ort, hipStream_t st) {
+	const long long n = p.oct[oct].plane;
+	hipLaunchKernelGGL(k_magort_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, img, oct, s, mag, ort);
+	return hipGetLastError();
+}
+
+hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
 	static bool attr_set = false;
 	size_t lds = pyramid_lds_bytes(p.halo);
 	if (!attr_set) {
@@ -286,7 +391,7 @@ hipError_t launch_pyramid(const SiftPlan& p, hipStream_t st) {
 		attr_set = true;
 	}
 	dim3 grid(p.total_tiles, p.n);
-	hipLaunchKernelGGL(k_pyramid, grid, dim3(256), lds, st, p);
+	hipLaunchKernelGGL(k_pyramid, grid, dim3(256), lds, st, p, raw, raw_count, cap);
 	return hipGetLastError();
 }
 

@@ -211,8 +211,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 
 	{ ProfScope ps(ctx, "resize"); HIPCHK(launch_resize_to_work(plan, st)); }
 	{ ProfScope ps(ctx, "octave grey"); HIPCHK(launch_octave_grey(plan, st)); }
-	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, st)); }
-	{ ProfScope ps(ctx, "extrema scan"); HIPCHK(launch_extrema_scan(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
+	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
 	{ ProfScope ps(ctx, "extrema refine");
 	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
 	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st)); }
@@ -448,8 +447,18 @@ int op_sift_dump_plane(op_ctx* ctx, const op_sift_dump* d, int kind, int oct, in
 	long long off;
 	if (kind == 5) off = plane_off_grey(o);
 	else if (kind == 1 && s >= 0 && s <= p.nscale - 2) off = plane_off_dog(o, s);
-	else if (kind == 2 && s >= 1 && s <= p.nscale - 3) off = plane_off_mag(o, p.nscale, s);
-	else if (kind == 3 && s >= 1 && s <= p.nscale - 3) off = plane_off_ort(o, p.nscale, s);
+	else if ((kind == 2 || kind == 3) && s >= 1 && s <= p.nscale - 3) {
+		// mag / ort planes are never materialised by the product path; the dump computes them
+		float* tmp = nullptr;
+		HIPCHK(hipMalloc(&tmp, sizeof(float) * 2 * (size_t)o.plane));
+		hipError_t e = launch_magort_plane(p, 0, oct, s, tmp, tmp + o.plane, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(out, tmp + (kind == 3 ? o.plane : 0), sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		hipFree(tmp);
+		if (e != hipSuccess) OP_FAIL(OP_ERR_HIP, std::string("op_sift_dump_plane: ") + hipGetErrorString(e));
+		return OP_OK;
+	}
+	else if (kind == 6 && s >= 1 && s <= p.nscale - 3) off = plane_off_gauss(o, p.nscale, s);
 	else OP_FAIL(OP_ERR_INVALID, "bad plane kind/scale");
 	HIPCHK(hipMemcpy(out, p.ws + off, sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost));
 	return OP_OK;
