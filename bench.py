@@ -162,8 +162,7 @@ def main():
         # fused scale space + extrema scan: grey in; 6 DoG + 4 Gaussian planes out (DESIGN.md section 3;
         # the scan runs on the DoG layers while they are in LDS and mag/ort are never materialised)
         "build pyramid": 4 * P + 24 * P + 16 * P,
-        "resize": 12 * H * W + 12 * wh * ww,
-        "octave grey": 12 * wh * ww + 4 * P,
+        "resize + octave grey": 12 * H * W + 4 * P,                      # source in, grey octave bases out (working image stays in LDS)
         "sift descriptor": (k_rank / nimg) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
         "orientation": (k_rank / nimg) * (8 * 16 * 16),
     }

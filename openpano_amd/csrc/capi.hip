@@ -31,6 +31,69 @@ void resolve_profile(op_ctx* c) {
 	c->pending.clear();
 }
 
+// ---- device allocation cache ----
+#include <map>
+#include <mutex>
+namespace {
+struct PoolState {
+	std::mutex mu;
+	std::multimap<std::pair<int, size_t>, void*> free_blocks;     // (device, size) -> block
+	std::map<void*, std::pair<int, size_t>> live;                  // block -> (device, size)
+	size_t cached_bytes = 0;
+};
+PoolState& pool() { static PoolState* p = new PoolState; return *p; }   // leaked on purpose: outlives static destructors
+size_t size_class(size_t b) {
+	if (b < 4096) return 4096;
+	size_t c = 4096;
+	while (c < b) c += (c >= (1u << 20) ? c / 4 : c);   // x2 up to 1 MiB, then +25 % steps
+	return c;
+}
+}	// namespace
+
+hipError_t pool_alloc(void** out, size_t bytes) {
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	const size_t cls = size_class(bytes ? bytes : 1);
+	PoolState& P = pool();
+	{
+		std::lock_guard<std::mutex> lk(P.mu);
+		auto it = P.free_blocks.find(std::make_pair(dev, cls));
+		if (it != P.free_blocks.end()) {
+			*out = it->second; P.free_blocks.erase(it); P.cached_bytes -= cls;
+			P.live[*out] = std::make_pair(dev, cls);
+			return hipSuccess;
+		}
+	}
+	e = hipMalloc(out, cls);
+	if (e != hipSuccess) {      // out of memory: give the cache back and retry once
+		pool_trim();
+		e = hipMalloc(out, cls);
+		if (e != hipSuccess) return e;
+	}
+	std::lock_guard<std::mutex> lk(P.mu);
+	P.live[*out] = std::make_pair(dev, cls);
+	return hipSuccess;
+}
+
+void pool_free(void* p) {
+	if (!p) return;
+	PoolState& P = pool();
+	std::lock_guard<std::mutex> lk(P.mu);
+	auto it = P.live.find(p);
+	if (it == P.live.end()) { hipFree(p); return; }
+	P.free_blocks.insert(std::make_pair(it->second, p));
+	P.cached_bytes += it->second.second;
+	P.live.erase(it);
+}
+
+void pool_trim() {
+	PoolState& P = pool();
+	std::lock_guard<std::mutex> lk(P.mu);
+	for (auto& kv : P.free_blocks) hipFree(kv.second);
+	P.free_blocks.clear(); P.cached_bytes = 0;
+}
+
 extern "C" {
 
 int op_ctx_set_profiling(op_ctx* c, int enable) {
@@ -103,6 +166,7 @@ void op_ctx_destroy(op_ctx* c) {
 	hipSetDevice(c->device);
 	hipStreamSynchronize(c->stream);
 	op_ctx_release_workspace(c);
+	pool_trim();
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
 	if (c->owns_stream) hipStreamDestroy(c->stream);

@@ -43,6 +43,13 @@ struct ProfScope {
 };
 void resolve_profile(op_ctx* c);
 
+// Size-class cache of device allocations (per device, process-wide, thread-safe): result buffers
+// (op_features, op_canvas) and per-call temporaries come from here, so a steady-state call does
+// no hipMalloc/hipFree (each costs tens of microseconds and synchronises the device).
+hipError_t pool_alloc(void** p, size_t bytes);
+void pool_free(void* p);
+void pool_trim();     // release every cached block back to the runtime
+
 // ---------------------------------------------------------------------------------------
 // HBM layout of one image's scale space ("image workspace", ws_stride floats per image):
 //   for each octave o:  [grey][DoG 0 .. ns-2][gauss 1 .. ns-3]   each h_o*w_o fp32, row-major,
@@ -68,7 +75,7 @@ struct SiftPlan {
 	int total_tiles;
 	long long ws_stride;        // floats per image workspace
 	float* ws;
-	float* work;                // n x wh x ww x 3
+	float* work;                // n x wh x ww x 3 (only materialised for the staged dump)
 	const float* const* srcs;   // device array of n source pointers (device memory)
 	// Gaussian bank (feature/gaussian.cc:17-40): kern[s][center + k], s = 1..nscale-1
 	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
@@ -101,8 +108,8 @@ struct KeyPoint {
 #endif
 
 // ---- kernel launchers (each returns hipGetLastError of its launch) ----
-hipError_t launch_resize_to_work(const SiftPlan& p, hipStream_t st);
-hipError_t launch_octave_grey(const SiftPlan& p, hipStream_t st);
+// source -> grey base of every octave (working image only written when write_work: staged dump)
+hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t st);
 // fused scale space + extrema scan: fills the DoG / Gaussian planes and appends raw extrema
 hipError_t launch_pyramid(const SiftPlan& p, int* raw /* n x cap x 4 */, int* raw_count /* n */, int cap, hipStream_t st);
 // debug/staged dump only: mag and ort of one Gaussian plane (GaussianPyramid::cal_mag_ort)

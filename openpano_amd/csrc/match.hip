@@ -272,14 +272,14 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	std::vector<int> h_res(std::max<long long>(res_rows, 1), -1);
 	int rc = OP_OK;
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
-	MCHK(hipMalloc(&d_norms, sizeof(float) * total));
-	MCHK(hipMalloc(&d_gmax, sizeof(unsigned)));
-	MCHK(hipMalloc(&d_top_s, sizeof(float) * 4 * std::max<long long>(top_rows, 1)));
-	MCHK(hipMalloc(&d_top_i, sizeof(int) * 4 * std::max<long long>(top_rows, 1)));
-	MCHK(hipMalloc(&d_res, sizeof(int) * std::max<long long>(res_rows, 1)));
-	MCHK(hipMalloc(&d_work, sizeof(WorkItem) * std::max<size_t>(work.size(), 1)));
-	MCHK(hipMalloc(&d_pds, sizeof(PairDesc) * npairs));
-	MCHK(hipMalloc(&d_blocks, sizeof(int2) * std::max<size_t>(blocks.size(), 1)));
+	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
+	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
+	MCHK(pool_alloc((void**)&d_top_s, sizeof(float) * 4 * std::max<long long>(top_rows, 1)));
+	MCHK(pool_alloc((void**)&d_top_i, sizeof(int) * 4 * std::max<long long>(top_rows, 1)));
+	MCHK(pool_alloc((void**)&d_res, sizeof(int) * std::max<long long>(res_rows, 1)));
+	MCHK(pool_alloc((void**)&d_work, sizeof(WorkItem) * std::max<size_t>(work.size(), 1)));
+	MCHK(pool_alloc((void**)&d_pds, sizeof(PairDesc) * npairs));
+	MCHK(pool_alloc((void**)&d_blocks, sizeof(int2) * std::max<size_t>(blocks.size(), 1)));
 	MCHK(hipMemsetAsync(d_gmax, 0, sizeof(unsigned), st));
 	MCHK(hipMemsetAsync(d_res, 0xff, sizeof(int) * std::max<long long>(res_rows, 1), st));
 	if (!work.empty()) MCHK(hipMemcpyAsync(d_work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
@@ -318,8 +318,8 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		m->total += (int64_t)v.size();
 	}
 done:
-	if (d_norms) hipFree(d_norms); if (d_gmax) hipFree(d_gmax); if (d_top_s) hipFree(d_top_s); if (d_top_i) hipFree(d_top_i);
-	if (d_res) hipFree(d_res); if (d_work) hipFree(d_work); if (d_pds) hipFree(d_pds); if (d_blocks) hipFree(d_blocks);
+	pool_free(d_norms); pool_free(d_gmax); pool_free(d_top_s); pool_free(d_top_i);
+	pool_free(d_res); pool_free(d_work); pool_free(d_pds); pool_free(d_blocks);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
 	*out = m;

@@ -29,55 +29,87 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
 	return rx * (p11 * ry + p10 * iry) + irx * (p01 * ry + p00 * iry);
 }
 
-// ---- K1: source (H x W x 3) -> working image (wh x ww x 3), feature/feature.cc:33-35 ----
-__global__ void __launch_bounds__(256) k_resize_to_work(SiftPlan p) {
-	const int img = blockIdx.z;
-	const int row = blockIdx.y;
-	const int col = blockIdx.x * 256 + threadIdx.x;
-	if (col >= p.ww) return;
-	const float fx = (float)p.wh / (float)p.sh, fy = (float)p.ww / (float)p.sw;
-	const float ifx = 1.f / fx, ify = 1.f / fy;
-	int sx, sy; float rx, ry;
-	resize_coord(row, ifx, p.sh, sx, rx);
-	resize_coord(col, ify, p.sw, sy, ry);
-	const float irx = 1.0f - rx, iry = 1.0f - ry;
-	const float* src = p.srcs[img];
-	const float* p0 = src + ((long long)sx * p.sw + sy) * 3;
-	const float* p1 = p0 + (long long)p.sw * 3;
-	float* dst = p.work + (((long long)img * p.wh + row) * p.ww + col) * 3;
-#pragma unroll
-	for (int c = 0; c < 3; ++c)
-		dst[c] = bilerp(p0[c], p0[3 + c], p1[c], p1[3 + c], rx, irx, ry, iry);
-}
+// ---- K1: source (H x W x 3) -> grey base of every octave, in one pass ------------------------
+// The reference resizes the source to the working image (feature/feature.cc:33-35), then resizes
+// that *working RGB image* once per octave (feature/dog.cc:105-110) and greys each result
+// (lib/imgproc.cc:237-249).  Here a workgroup computes a WT x WR tile of the working image (+1
+// row / column for the bilinear taps) from the source straight into LDS, greys it for octave 0
+// and emits every pixel of octaves 1.. whose bilinear footprint starts inside the tile (each
+// octave pixel has exactly one such tile).  The working image never goes to HBM (the staged dump
+// asks for it with write_work); every value is computed by the reference's formulas, so the grey
+// planes are bit-identical to the two-pass result.
+constexpr int WT = 64, WR = 16;               // working-image tile
+constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 
-// ---- K2: working image -> grey base of every octave (feature/dog.cc:96-114, :48-51) ----
-__global__ void __launch_bounds__(256) k_octave_grey(SiftPlan p) {
+__global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work) {
+	__shared__ float s_rgb[3][(WR + 1) * WP];
 	const int img = blockIdx.z;
-	const int o = blockIdx.y;
-	const OctDesc od = p.oct[o];
-	const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-	if (idx >= od.plane) return;
-	const int row = (int)(idx / od.w), col = (int)(idx % od.w);
-	const float* work = p.work + (long long)img * p.wh * p.ww * 3;
-	float r, g, b;
-	if (o == 0) {
-		const float* q = work + idx * 3;
-		r = q[0]; g = q[1]; b = q[2];
-	} else {
+	const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WR;
+	const int tid = threadIdx.x;
+	const float* src = p.srcs[img];
+	// working-image tile: lib/imgproc.cc:22-80 on the source
+	{
+		const float fx = (float)p.wh / (float)p.sh, fy = (float)p.ww / (float)p.sw;
+		const float ifx = 1.f / fx, ify = 1.f / fy;
+		for (int e = tid; e < (WR + 1) * (WT + 1); e += 256) {
+			const int r = e / (WT + 1), c = e % (WT + 1);
+			const int row = ty0 + r, col = tx0 + c;
+			float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+			if (row < p.wh && col < p.ww) {
+				int sx, sy; float rx, ry;
+				resize_coord(row, ifx, p.sh, sx, rx);
+				resize_coord(col, ify, p.sw, sy, ry);
+				const float irx = 1.0f - rx, iry = 1.0f - ry;
+				const float* p0 = src + ((long long)sx * p.sw + sy) * 3;
+				const float* p1 = p0 + (long long)p.sw * 3;
+				v0 = bilerp(p0[0], p0[3], p1[0], p1[3], rx, irx, ry, iry);
+				v1 = bilerp(p0[1], p0[4], p1[1], p1[4], rx, irx, ry, iry);
+				v2 = bilerp(p0[2], p0[5], p1[2], p1[5], rx, irx, ry, iry);
+				if (write_work && r < WR && c < WT) {
+					float* dst = p.work + (((long long)img * p.wh + row) * p.ww + col) * 3;
+					dst[0] = v0; dst[1] = v1; dst[2] = v2;
+				}
+			}
+			s_rgb[0][r * WP + c] = v0; s_rgb[1][r * WP + c] = v1; s_rgb[2][r * WP + c] = v2;
+		}
+	}
+	__syncthreads();
+	float* ws = p.ws + (long long)img * p.ws_stride;
+	// octave 0: grey of the working tile (lib/imgproc.cc:245)
+	for (int e = tid; e < WR * WT; e += 256) {
+		const int r = e / WT, c = e % WT;
+		const int row = ty0 + r, col = tx0 + c;
+		if (row < p.wh && col < p.ww)
+			ws[plane_off_grey(p.oct[0]) + (long long)row * p.ww + col] =
+				(s_rgb[0][r * WP + c] + s_rgb[1][r * WP + c] + s_rgb[2][r * WP + c]) / 3.f;
+	}
+	// octaves 1..: pixels whose top-left tap (sx, sy) lies in this tile
+	for (int o = 1; o < p.noct; ++o) {
+		const OctDesc od = p.oct[o];
 		const float fx = (float)od.h / (float)p.wh, fy = (float)od.w / (float)p.ww;
 		const float ifx = 1.f / fx, ify = 1.f / fy;
-		int sx, sy; float rx, ry;
-		resize_coord(row, ifx, p.wh, sx, rx);
-		resize_coord(col, ify, p.ww, sy, ry);
-		const float irx = 1.0f - rx, iry = 1.0f - ry;
-		const float* p0 = work + ((long long)sx * p.ww + sy) * 3;
-		const float* p1 = p0 + (long long)p.ww * 3;
-		r = bilerp(p0[0], p0[3], p1[0], p1[3], rx, irx, ry, iry);
-		g = bilerp(p0[1], p0[4], p1[1], p1[4], rx, irx, ry, iry);
-		b = bilerp(p0[2], p0[5], p1[2], p1[5], rx, irx, ry, iry);
+		// conservative candidate rectangle (membership is decided exactly below)
+		int r_lo = (int)floorf(((float)ty0 + 0.5f) * fx - 0.5f) - 1, r_hi = (int)ceilf(((float)(ty0 + WR) + 0.5f) * fx - 0.5f) + 2;
+		int c_lo = (int)floorf(((float)tx0 + 0.5f) * fy - 0.5f) - 1, c_hi = (int)ceilf(((float)(tx0 + WT) + 0.5f) * fy - 0.5f) + 2;
+		r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
+		r_hi = r_hi > od.h ? od.h : r_hi; c_hi = c_hi > od.w ? od.w : c_hi;
+		const int nr = r_hi - r_lo, nc = c_hi - c_lo;
+		if (nr <= 0 || nc <= 0) continue;
+		for (int e = tid; e < nr * nc; e += 256) {
+			const int dr = r_lo + e / nc, dc = c_lo + e % nc;
+			int sx, sy; float rx, ry;
+			resize_coord(dr, ifx, p.wh, sx, rx);
+			resize_coord(dc, ify, p.ww, sy, ry);
+			const int lr = sx - ty0, lc = sy - tx0;
+			if (lr < 0 || lr >= WR || lc < 0 || lc >= WT) continue;
+			const float irx = 1.0f - rx, iry = 1.0f - ry;
+			const int b = lr * WP + lc;
+			const float r = bilerp(s_rgb[0][b], s_rgb[0][b + 1], s_rgb[0][b + WP], s_rgb[0][b + WP + 1], rx, irx, ry, iry);
+			const float g = bilerp(s_rgb[1][b], s_rgb[1][b + 1], s_rgb[1][b + WP], s_rgb[1][b + WP + 1], rx, irx, ry, iry);
+			const float bl = bilerp(s_rgb[2][b], s_rgb[2][b + 1], s_rgb[2][b + WP], s_rgb[2][b + WP + 1], rx, irx, ry, iry);
+			ws[plane_off_grey(od) + (long long)dr * od.w + dc] = (r + g + bl) / 3.f;   // lib/imgproc.cc:245
+		}
 	}
-	float* ws = p.ws + (long long)img * p.ws_stride;
-	ws[plane_off_grey(od) + idx] = (r + g + b) / 3.f;   // lib/imgproc.cc:245
 }
 
 // ---- K3: fused scale space -----------------------------------------------------------
@@ -364,15 +396,9 @@ size_t pyramid_lds_bytes(int halo) {
 	return sizeof(float) * ((size_t)NR * NC + (size_t)NC * PV + 4 * (size_t)GR * PG);
 }
 
-hipError_t launch_resize_to_work(const SiftPlan& p, hipStream_t st) {
-	dim3 grid((p.ww + 255) / 256, p.wh, p.n);
-	hipLaunchKernelGGL(k_resize_to_work, grid, dim3(256), 0, st, p);
-	return hipGetLastError();
-}
-
-hipError_t launch_octave_grey(const SiftPlan& p, hipStream_t st) {
-	dim3 grid((unsigned)((p.oct[0].plane + 255) / 256), p.noct, p.n);
-	hipLaunchKernelGGL(k_octave_grey, grid, dim3(256), 0, st, p);
+hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t st) {
+	dim3 grid((p.ww + WT - 1) / WT, (p.wh + WR - 1) / WR, p.n);
+	hipLaunchKernelGGL(k_grey_octaves, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
 	return hipGetLastError();
 }
 

@@ -168,7 +168,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 
 	// --- buffers
 	HIPCHK(W.ws.ensure(sizeof(float) * (size_t)plan.ws_stride * n));
-	HIPCHK(W.work.ensure(sizeof(float) * (size_t)plan.wh * plan.ww * 3 * n));
+	if (keep) HIPCHK(W.work.ensure(sizeof(float) * (size_t)plan.wh * plan.ww * 3 * n));
 	HIPCHK(W.srcs.ensure(sizeof(float*) * n));
 	HIPCHK(W.raw.ensure(sizeof(int) * 4 * (size_t)cap * n));
 	HIPCHK(W.counts.ensure(sizeof(int) * 4 * n));            // raw | refined | oriented | spare
@@ -209,8 +209,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	int* d_oriented_count = d_raw_count + 2 * n;
 	HIPCHK(hipMemsetAsync(W.counts.p, 0, sizeof(int) * 4 * n, st));
 
-	{ ProfScope ps(ctx, "resize"); HIPCHK(launch_resize_to_work(plan, st)); }
-	{ ProfScope ps(ctx, "octave grey"); HIPCHK(launch_octave_grey(plan, st)); }
+	{ ProfScope ps(ctx, "resize + octave grey"); HIPCHK(launch_grey_octaves(plan, keep != nullptr, st)); }
 	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
 	{ ProfScope ps(ctx, "extrema refine");
 	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
@@ -237,9 +236,9 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	HIPCHK(hipMemcpyAsync(W.offsets.p, h_off, sizeof(long long) * (n + 1), hipMemcpyHostToDevice, st));
 	res.total = total;
 	HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(hipMalloc(&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(hipMalloc(&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(hipMalloc(&res.real, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(pool_alloc((void**)&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(pool_alloc((void**)&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+	HIPCHK(pool_alloc((void**)&res.real, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
 	{ ProfScope ps(ctx, "orientation");
 	  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
 				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st)); }
@@ -294,7 +293,7 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 		SiftPlan plan;
 		int rc = run_group(ctx, *cfg, gi, *W, plan, results[g], nullptr);
 		if (rc != OP_OK) {
-			for (auto& r : results) { if (r.desc) hipFree(r.desc); if (r.coor) hipFree(r.coor); if (r.real) hipFree(r.real); }
+			for (auto& r : results) { pool_free(r.desc); pool_free(r.coor); pool_free(r.real); }
 			delete f; return rc;
 		}
 		for (size_t k = 0; k < gi.size(); ++k) f->counts[groups[g].second[k]] = results[g].counts[k];
@@ -305,9 +304,9 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 	if (groups.size() == 1) {
 		f->desc = results[0].desc; f->coor = results[0].coor; f->real = results[0].real;
 	} else {
-		HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
-		HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
-		HIPCHK(hipMalloc(&f->real, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+		HIPCHK(pool_alloc((void**)&f->desc, sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1)));
+		HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+		HIPCHK(pool_alloc((void**)&f->real, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
 		for (size_t g = 0; g < groups.size(); ++g) {
 			long long go = 0;
 			for (size_t k = 0; k < groups[g].second.size(); ++k) {
@@ -321,7 +320,7 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 			}
 		}
 		HIPCHK(hipStreamSynchronize(ctx->stream));
-		for (auto& r : results) { hipFree(r.desc); hipFree(r.coor); hipFree(r.real); }
+		for (auto& r : results) { pool_free(r.desc); pool_free(r.coor); pool_free(r.real); }
 	}
 	*out = f;
 	return OP_OK;
@@ -365,8 +364,8 @@ int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* c
 	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
 	f->offsets[n] = total;
 	f->has_desc = desc != nullptr;       // coordinates only: enough for op_ransac_pairs, rejected by op_match_pairs
-	HIPCHK(hipMalloc(&f->desc, f->has_desc ? sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1) : sizeof(float)));
-	HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
+	HIPCHK(pool_alloc((void**)&f->desc, f->has_desc ? sizeof(float) * 128 * (size_t)std::max<int64_t>(total, 1) : sizeof(float)));
+	HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1)));
 	HIPCHK(hipMemsetAsync(f->coor, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(total, 1), ctx->stream));
 	for (int i = 0; i < n; ++i) {
 		if (!counts[i]) continue;
@@ -387,8 +386,8 @@ int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* co
 	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
 	f->offsets[n] = total;
 	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
-	HIPCHK(hipMalloc(&f->desc, sizeof(float) * 128 * cnt));
-	HIPCHK(hipMalloc(&f->coor, sizeof(double) * 2 * cnt));
+	HIPCHK(pool_alloc((void**)&f->desc, sizeof(float) * 128 * cnt));
+	HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt));
 	if (total) HIPCHK(hipMemcpyAsync(f->desc, desc_dev, sizeof(float) * 128 * total, hipMemcpyDeviceToDevice, ctx->stream));
 	if (coor_dev && total) HIPCHK(hipMemcpyAsync(f->coor, coor_dev, sizeof(double) * 2 * total, hipMemcpyDeviceToDevice, ctx->stream));
 	else HIPCHK(hipMemsetAsync(f->coor, 0, sizeof(double) * 2 * cnt, ctx->stream));
@@ -400,9 +399,7 @@ int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* co
 void op_features_free(op_features* f) {
 	if (!f) return;
 	hipSetDevice(f->device);
-	if (f->desc) hipFree(f->desc);
-	if (f->coor) hipFree(f->coor);
-	if (f->real) hipFree(f->real);
+	pool_free(f->desc); pool_free(f->coor); pool_free(f->real);
 	delete f;
 }
 
@@ -418,9 +415,7 @@ int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_si
 		d->coor01.resize((size_t)res.total * 2);
 		for (long long i = 0; i < res.total; ++i) { d->coor01[2 * i] = d->oriented[i].rx; d->coor01[2 * i + 1] = d->oriented[i].ry; }
 	}
-	if (res.desc) hipFree(res.desc);
-	if (res.coor) hipFree(res.coor);
-	if (res.real) hipFree(res.real);
+	pool_free(res.desc); pool_free(res.coor); pool_free(res.real);
 	if (rc != OP_OK) { d->w.release(); delete d; return rc; }
 	*out = d;
 	return OP_OK;
