@@ -5,18 +5,12 @@
 // FeatureMatcher::match (feature/matcher.cc:15-71) -- see SURVEY.md F2/F3 for why the
 // kd-forest's approximate, non-deterministic answers cannot be the parity target.
 //
-// Two kernels for ALL requested image pairs at once:
-//  k_match_top4   fp32 MFMA (v_mfma_f32_32x32x2_f32) dot-product tiles; the epilogue keeps, for
-//                 every descriptor x of set X, the 4 best columns of set Y by
-//                 score = x.y - |y|^2/2  (= const - d(x,y)/2).  Run for both directions of a pair.
-//                 MFMA results only RANK candidates; they never decide a match.
-//  k_match_decide per row of the smaller set: re-scores the candidates with the reference's
-//                 exact squared-L2 (feature/dist.cc:22-57: four stride-4 fp32 partial sums,
-//                 (v0+v1)+(v2+v3)), applies both ratio tests with the reference's float
-//                 arithmetic.  Candidate sets are provably complete: every column whose score is
-//                 within E of the 2nd best is re-scored, where E bounds twice the worst-case
-//                 fp32 error of score vs. exact distance; if all 4 kept entries fall inside the
-//                 margin the row falls back to an exact full scan.
+// ALL requested image pairs go through two launches of one fp32-MFMA sweep kernel
+// (v_mfma_f32_32x32x2_f32 dot-product tiles, running per-row top-4 by score = x.y - |y|^2/2):
+// a forward sweep of every row of the smaller set, whose epilogue re-scores the ranked
+// candidates with the reference's exact squared L2 and applies the first ratio test, and a
+// reverse sweep over the survivors only, whose epilogue applies the second test.  MFMA results
+// only RANK candidates; the reference's float arithmetic decides every match.
 #include "internal.hpp"
 #include <cfloat>
 #include <algorithm>
@@ -38,7 +32,16 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct WorkItem { int x_off, kx, y_off, ky, rowblock, out_off; };   // offsets in descriptors
+// One MFMA sweep kernel serves both directions of FeatureMatcher::match:
+//   FWD  rows = every descriptor of the smaller set A, columns = B: exact 2-NN + the first ratio
+//        test (feature/matcher.cc:33-55); rows that pass are appended to the pair's survivor list;
+//   REV  rows = the best matches b* of the survivors only (typically a few percent of A),
+//        columns = A: min over a' != a of d(b*, a') folded into next_min and the second ratio
+//        test (matcher.cc:57-63).
+// so the dense contraction runs once per unordered pair plus a small reverse strip, i.e. the
+// algorithmic 2*128*K_i*K_j flop of SURVEY 8(d) instead of twice that.
+struct WorkItem { int pair, rowblock; };
+struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; };
 
 constexpr int YP = 132;   // LDS pitch of a Y tile row (floats): 16-B slot rotation -> conflict-free b128
 
@@ -52,95 +55,16 @@ __global__ void __launch_bounds__(256) k_norms(const float* desc, long long tota
 	atomicMax(gmax_bits, __float_as_uint(s));
 }
 
-__device__ __forceinline__ void top4_insert(float (&ts)[4], int (&ti)[4], float s, int idx) {
-	if (!(s > ts[3])) return;
-	if (s > ts[0]) { ts[3] = ts[2]; ti[3] = ti[2]; ts[2] = ts[1]; ti[2] = ti[1]; ts[1] = ts[0]; ti[1] = ti[0]; ts[0] = s; ti[0] = idx; }
-	else if (s > ts[1]) { ts[3] = ts[2]; ti[3] = ti[2]; ts[2] = ts[1]; ti[2] = ti[1]; ts[1] = s; ti[1] = idx; }
-	else if (s > ts[2]) { ts[3] = ts[2]; ti[3] = ti[2]; ts[2] = s; ti[2] = idx; }
-	else { ts[3] = s; ti[3] = idx; }
-}
-
-// One workgroup = 128 rows of X (4 waves x 32 rows, X fragments resident in VGPRs) against all
-// of Y, streamed through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
-// holding 16 scores of ONE X row (C/D layout: col = lane&31), which makes the running top-4 a
-// purely per-lane update; the two lane halves are merged once at the end.
-__global__ void __launch_bounds__(256) k_match_top4(const float* __restrict__ desc, const float* __restrict__ norms,
-		const WorkItem* __restrict__ work, float* __restrict__ top_s, int* __restrict__ top_i) {
-	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
-	__shared__ float s_nyh[2][32];
-	__shared__ float s_ms[4][32][2][4];
-	__shared__ int s_mi[4][32][2][4];
-	const WorkItem wk = work[blockIdx.x];
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int j = lane & 31, h = lane >> 5;
-	const float* X = desc + (long long)wk.x_off * 128;
-	const float* Y = desc + (long long)wk.y_off * 128;
-	const float* ny = norms + wk.y_off;
-	const int row = wk.rowblock * 128 + wave * 32 + j;
-	const int rowc = row < wk.kx ? row : wk.kx - 1;
-	// X fragment: row j, k in [64h, 64h+64)
-	f32x4 xf[16];
-	{
-		const f32x4* px = (const f32x4*)(X + (long long)rowc * 128 + 64 * h);
+// running top-NK (descending score); the common case is the single rejecting compare
+constexpr int NK = 8;
+__device__ __forceinline__ void topk_insert(float (&ts)[NK], int (&ti)[NK], float s, int idx) {
+	if (!(s > ts[NK - 1])) return;
 #pragma unroll
-		for (int q = 0; q < 16; ++q) xf[q] = px[q];
-	}
-	float ts[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-	int ti[4] = {-1, -1, -1, -1};
-	const int ntiles = (wk.ky + 31) / 32;
-
-	auto load_tile = [&](int t, int buf) {
-		// 32 rows x 128 floats = 1024 float4, 4 per thread
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int e = tid + 256 * r;          // float4 index
-			const int yr = e >> 5, c4 = e & 31;
-			const int gy = t * 32 + yr;
-			f32x4 v = {0.f, 0.f, 0.f, 0.f};
-			if (gy < wk.ky) v = *(const f32x4*)(Y + (long long)gy * 128 + c4 * 4);
-			*(f32x4*)(&s_y[buf][yr * YP + c4 * 4]) = v;
-		}
-		if (tid < 32) {
-			const int gy = t * 32 + tid;
-			s_nyh[buf][tid] = gy < wk.ky ? 0.5f * ny[gy] : FLT_MAX;   // padded columns can never rank
-		}
-	};
-
-	load_tile(0, 0);
-	__syncthreads();
-	for (int t = 0; t < ntiles; ++t) {
-		const int buf = t & 1;
-		if (t + 1 < ntiles) load_tile(t + 1, buf ^ 1);
-		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-		const float* yrow = &s_y[buf][j * YP + 64 * h];
-#pragma unroll
-		for (int q = 0; q < 16; ++q) {
-			const f32x4 a = *(const f32x4*)(yrow + 4 * q);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xf[q].x, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xf[q].y, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xf[q].z, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xf[q].w, acc, 0, 0, 0);
-		}
-		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
-#pragma unroll
-		for (int reg = 0; reg < 16; ++reg) {
-			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			const float s = acc[reg] - s_nyh[buf][i];
-			top4_insert(ts, ti, s, t * 32 + i);
-		}
-		__syncthreads();
-	}
-	// merge the two lane halves of each X row
-#pragma unroll
-	for (int r = 0; r < 4; ++r) { s_ms[wave][j][h][r] = ts[r]; s_mi[wave][j][h][r] = ti[r]; }
-	__syncthreads();
-	if (h == 0 && row < wk.kx) {
-#pragma unroll
-		for (int r = 0; r < 4; ++r) top4_insert(ts, ti, s_ms[wave][j][1][r], s_mi[wave][j][1][r]);
-		float* os = top_s + ((long long)wk.out_off + row) * 4;
-		int* oi = top_i + ((long long)wk.out_off + row) * 4;
-#pragma unroll
-		for (int r = 0; r < 4; ++r) { os[r] = ts[r]; oi[r] = ti[r]; }
+	for (int r = NK - 1; r >= 0; --r) {
+		const bool up = r > 0 && s > ts[r - 1];       // the new entry belongs above slot r: shift down
+		const float ns = up ? ts[r - 1] : s; const int ni = up ? ti[r - 1] : idx;
+		const bool here = s > ts[r];                  // slots below the insertion point are rewritten
+		ts[r] = here ? ns : ts[r]; ti[r] = here ? ni : ti[r];
 	}
 }
 
@@ -161,71 +85,246 @@ __device__ __forceinline__ float euclidean_sqr_exact(const float* __restrict__ x
 	return (v0 + v1) + (v2 + v3);
 }
 
-struct PairDesc { int a_off, ka, b_off, kb; int topA_off, topB_off; int res_off; int rev; };
+// device-side state of one op_match_pairs call
+struct MatchState {
+	const float* desc; const float* norms; const unsigned* gmax_bits;
+	const PairDesc* pairs;
+	int* fb;            // per A row: forward best column b*, -1 rejected, -2 needs the exact full scan
+	float* fmn;         // per A row: exact min distance
+	float* fnext;       // per A row: exact second-min distance
+	int* surv;          // per pair region (res_off .. res_off+ka): A rows that passed the first ratio test
+	int* nsurv;         // per pair
+	int* res;           // per A row: final match column or -1
+	int* slow_fwd; int* slow_rev;   // rows needing a full scan: [0] = count, then (pair, row) pairs
+	int slow_cap;
+	float rr;           // MATCH_REJECT_NEXT_RATIO^2 (matcher.cc:16)
+};
 
-// thread per row of the smaller set (FeatureMatcher::match body, feature/matcher.cc:33-67)
-__global__ void __launch_bounds__(128) k_match_decide(const float* __restrict__ desc, const float* __restrict__ norms,
-		const unsigned* __restrict__ gmax_bits, const PairDesc* __restrict__ pairs, const int2* __restrict__ blocks,
-		const float* __restrict__ top_s, const int* __restrict__ top_i, float reject_ratio_sqr, int* __restrict__ res) {
-	const int2 blk = blocks[blockIdx.x];
-	const PairDesc pd = pairs[blk.x];
-	const int a = blk.y * 128 + threadIdx.x;
-	if (a >= pd.ka) return;
-	const float* A = desc + (long long)pd.a_off * 128;
-	const float* B = desc + (long long)pd.b_off * 128;
-	const float* xa = A + (long long)a * 128;
-	const float gmax = __uint_as_float(*gmax_bits);
-	// ---- forward: exact top-2 of row a over B
-	float mn = FLT_MAX, next_min = FLT_MAX; int min_idx = -1;
+// FeatureMatcher::match, first ratio test (matcher.cc:52); survivors are queued for the reverse pass
+__device__ __forceinline__ void finish_forward(const MatchState& S, const PairDesc& pd, int pair, int a, float mn, float next_min, int min_idx) {
+	const long long o = (long long)pd.res_off + a;
+	S.fmn[o] = mn; S.fnext[o] = next_min;
+	if (min_idx >= 0 && !(mn > S.rr * next_min)) {
+		S.fb[o] = min_idx;
+		const int slot = atomicAdd(&S.nsurv[pair], 1);
+		S.surv[pd.res_off + slot] = a;
+	} else S.fb[o] = -1;
+}
+// second ratio test (matcher.cc:62)
+__device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDesc& pd, int a, float next_min) {
+	const long long o = (long long)pd.res_off + a;
+	if (!(S.fmn[o] > S.rr * next_min)) S.res[o] = S.fb[o];
+}
+
+// One workgroup = 128 rows of X (4 waves x 32 rows, X fragments resident in VGPRs) against all
+// of Y, streamed through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
+// holding 16 scores of ONE X row (C/D layout: col = lane&31), which makes the running top-4 a
+// purely per-lane update; the two lane halves (k < 64 / k >= 64 of the row) are merged once at
+// the end.  MFMA scores (x.y - |y|^2/2 = const - d/2) only RANK columns.  The epilogue then
+// re-scores the <= 4 ranked candidates of every row with the reference's exact squared L2
+// (feature/dist.cc:22-57: four stride-4 fp32 partial sums walked in order, (v0+v1)+(v2+v3)):
+// the row is still in registers, split across the two lane halves exactly at t = 16, so the
+// lower half walks t = 0..15, hands its four partial sums to the upper half, which walks
+// t = 16..31 -- candidates are software-pipelined through the two halves.  The candidate set is
+// provably complete: every column whose score is within E of the 2nd best is re-scored, where E
+// bounds twice the worst-case fp32 error of score vs. exact distance; if all 4 kept entries
+// fall inside the margin the row is queued for an exact full scan instead.
+template <bool REV>
+__global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
+	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
+	__shared__ float s_nyh[2][32];
+	__shared__ float s_ms[4][32][2][NK];
+	__shared__ int s_mi[4][32][2][NK];
+	const WorkItem wk = work[blockIdx.x];
+	const PairDesc pd = S.pairs[wk.pair];
+	const int nrows = REV ? S.nsurv[wk.pair] : pd.ka;
+	if (wk.rowblock * 128 >= nrows) return;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int j = lane & 31, h = lane >> 5;
+	const float* A = S.desc + (long long)pd.a_off * 128;
+	const float* B = S.desc + (long long)pd.b_off * 128;
+	const float* Y = REV ? A : B;
+	const int ky = REV ? pd.ka : pd.kb;
+	const float* ny = S.norms + (REV ? pd.a_off : pd.b_off);
+	const int row = wk.rowblock * 128 + wave * 32 + j;
+	const int rowc = row < nrows ? row : nrows - 1;
+	// the X row: FWD a = rowc ; REV a = survivor, X = B[b*(a)]
+	const int a_row = REV ? S.surv[pd.res_off + rowc] : rowc;
+	const int x_idx = REV ? S.fb[pd.res_off + a_row] : a_row;
+	const float* X = (REV ? B : A) + (long long)x_idx * 128;
+	f32x4 xf[16];     // row elements [64h, 64h+64)
 	{
-		const float* s = top_s + ((long long)pd.topA_off + a) * 4;
-		const int* ix = top_i + ((long long)pd.topA_off + a) * 4;
-		const float E = 3.2e-5f * (norms[pd.a_off + a] + gmax);
-		const float thr = s[1] - E;
-		const bool overflow = ix[3] >= 0 && s[3] >= thr;
-		if (overflow || pd.kb <= 4) {
-			for (int kk = 0; kk < pd.kb; ++kk) {
-				const float d = euclidean_sqr_exact(xa, B + (long long)kk * 128);
-				if (d < mn) { next_min = mn; mn = d; min_idx = kk; }
-				else if (d < next_min) next_min = d;
-			}
-		} else {
-			// candidates in ascending column order so that ties resolve to the first index (:42-48)
-			int c[4]; int nc = 0;
+		const f32x4* px = (const f32x4*)(X + 64 * h);
 #pragma unroll
-			for (int r = 0; r < 4; ++r) if (ix[r] >= 0 && s[r] >= thr) c[nc++] = ix[r];
-			for (int u = 1; u < nc; ++u) { int v = c[u], w = u; while (w > 0 && c[w - 1] > v) { c[w] = c[w - 1]; --w; } c[w] = v; }
-			for (int u = 0; u < nc; ++u) {
-				const float d = euclidean_sqr_exact(xa, B + (long long)c[u] * 128);
-				if (d < mn) { next_min = mn; mn = d; min_idx = c[u]; }
-				else if (d < next_min) next_min = d;
-			}
+		for (int q = 0; q < 16; ++q) xf[q] = px[q];
+	}
+	float ts[NK]; int ti[NK];
+#pragma unroll
+	for (int r = 0; r < NK; ++r) { ts[r] = -FLT_MAX; ti[r] = -1; }
+	const int ntiles = (ky + 31) / 32;
+
+	auto load_tile = [&](int t, int buf) {
+		// 32 rows x 128 floats = 1024 float4, 4 per thread
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int e = tid + 256 * r;          // float4 index
+			const int yr = e >> 5, c4 = e & 31;
+			const int gy = t * 32 + yr;
+			f32x4 v = {0.f, 0.f, 0.f, 0.f};
+			if (gy < ky) v = *(const f32x4*)(Y + (long long)gy * 128 + c4 * 4);
+			*(f32x4*)(&s_y[buf][yr * YP + c4 * 4]) = v;
+		}
+		if (tid < 32) {
+			const int gy = t * 32 + tid;
+			s_nyh[buf][tid] = gy < ky ? 0.5f * ny[gy] : FLT_MAX;   // padded columns can never rank
+		}
+	};
+
+	load_tile(0, 0);
+	__syncthreads();
+	for (int t = 0; t < ntiles; ++t) {
+		const int buf = t & 1;
+		if (t + 1 < ntiles) load_tile(t + 1, buf ^ 1);
+		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		const float* yrow = &s_y[buf][j * YP + 64 * h];
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			const f32x4 av = *(const f32x4*)(yrow + 4 * q);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xf[q].x, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xf[q].y, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xf[q].z, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xf[q].w, acc, 0, 0, 0);
+		}
+		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
+#pragma unroll
+		for (int reg = 0; reg < 16; ++reg) {
+			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+			const float sc = acc[reg] - s_nyh[buf][i];
+			topk_insert(ts, ti, sc, t * 32 + i);
+		}
+		__syncthreads();
+	}
+	// merge the two lane halves of each X row; both halves then read the merged top-4
+#pragma unroll
+	for (int r = 0; r < NK; ++r) { s_ms[wave][j][h][r] = ts[r]; s_mi[wave][j][h][r] = ti[r]; }
+	__syncthreads();
+	if (h == 0) {
+#pragma unroll
+		for (int r = 0; r < NK; ++r) topk_insert(ts, ti, s_ms[wave][j][1][r], s_mi[wave][j][1][r]);
+#pragma unroll
+		for (int r = 0; r < NK; ++r) { s_ms[wave][j][0][r] = ts[r]; s_mi[wave][j][0][r] = ti[r]; }
+	}
+	__syncthreads();
+
+	// ---- candidate set (identical in both halves): merged top-NK entries within E of the 2nd best ----
+	const float gmax = __uint_as_float(*S.gmax_bits);
+	const float E = 3.2e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
+	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];
+	const float thr = ms[1] - E;
+	const bool overflow = mi[NK - 1] >= 0 && ms[NK - 1] >= thr;     // even the NK-th entry is inside the margin
+	int c[NK]; int nc = 0;
+#pragma unroll
+	for (int r = 0; r < NK; ++r) c[r] = 0x7fffffff;
+#pragma unroll
+	for (int r = 0; r < NK; ++r) {
+		const int ci = mi[r];
+		if (ci >= 0 && ms[r] >= thr && !(REV && ci == a_row)) {      // REV: kk != k (matcher.cc:58)
+			// insertion into ascending column order: distance ties resolve to the first index (matcher.cc:42-48)
+			int v = ci;
+#pragma unroll
+			for (int q = 0; q < NK; ++q) { const int o = c[q]; const bool sw = v < o; c[q] = sw ? v : o; v = sw ? o : v; }
+			++nc;
 		}
 	}
-	int out = -1;
-	if (min_idx >= 0 && !(mn > reject_ratio_sqr * next_min)) {             // :52
-		// ---- reverse: min over a' != a of d(b*, a'), folded into next_min (:57-61)
-		const float* xb = B + (long long)min_idx * 128;
-		const float* s = top_s + ((long long)pd.topB_off + min_idx) * 4;
-		const int* ix = top_i + ((long long)pd.topB_off + min_idx) * 4;
-		const float E = 3.2e-5f * (norms[pd.b_off + min_idx] + gmax);
-		const float thr = s[1] - E;
-		const bool overflow = ix[3] >= 0 && s[3] >= thr;
-		if (overflow || pd.ka <= 4) {
-			for (int kk = 0; kk < pd.ka; ++kk) if (kk != a) {
-				const float d = euclidean_sqr_exact(xb, A + (long long)kk * 128);
-				if (d < next_min) next_min = d;
-			}
-		} else {
+	const bool live = row < nrows;
+	if (overflow) nc = 0;
+	int ncmax = nc;                    // wave-uniform trip count
 #pragma unroll
-			for (int r = 0; r < 4; ++r) if (ix[r] >= 0 && ix[r] != a && s[r] >= thr) {
-				const float d = euclidean_sqr_exact(xb, A + (long long)ix[r] * 128);
-				if (d < next_min) next_min = d;
+	for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(ncmax, off); ncmax = o > ncmax ? o : ncmax; }
+
+	// ---- exact re-score, pipelined through the lane halves ----
+	float mn = REV ? 0.f : FLT_MAX, next_min = FLT_MAX; int min_idx = -1;
+	if (REV) next_min = S.fnext[pd.res_off + a_row];
+	float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+	for (int u = 0; u <= ncmax; ++u) {
+		// lower half: first 64 elements of candidate u ; upper half: last 64 of candidate u-1
+		const int cu = h == 0 ? u : u - 1;
+		const bool act = cu >= 0 && cu < nc;
+		float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+		if (h == 1) { w0 = v0; w1 = v1; w2 = v2; w3 = v3; }      // partial sums handed over below
+		int ccol = 0;
+#pragma unroll
+		for (int r = 0; r < NK; ++r) ccol = (cu == r) ? c[r] : ccol;
+		if (act) {
+			const f32x4* py = (const f32x4*)(Y + (long long)ccol * 128 + 64 * h);
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {      // static indices keep the row in VGPRs; 4 loads in flight at a time
+				const f32x4 b = py[q];
+				float d;
+				d = xf[q].x - b.x; w0 += d * d;
+				d = xf[q].y - b.y; w1 += d * d;
+				d = xf[q].z - b.z; w2 += d * d;
+				d = xf[q].w - b.w; w3 += d * d;
+				if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		if (!(mn > reject_ratio_sqr * next_min)) out = min_idx;             // :62
+		if (h == 1 && act) {
+			const float d = (w0 + w1) + (w2 + w3);
+			if (REV) { if (d < next_min) next_min = d; }
+			else if (d < mn) { next_min = mn; mn = d; min_idx = ccol; }
+			else if (d < next_min) next_min = d;
+		}
+		// hand the lower half's partial sums to the upper half (lane j -> lane j + 32)
+		v0 = __shfl(w0, j); v1 = __shfl(w1, j); v2 = __shfl(w2, j); v3 = __shfl(w3, j);
 	}
-	res[pd.res_off + a] = out;
+	if (h == 1 && live) {
+		if (overflow) {
+			int* q = REV ? S.slow_rev : S.slow_fwd;
+			const int slot = atomicAdd(&q[0], 1);
+			if (slot < S.slow_cap) { q[1 + 2 * slot] = wk.pair; q[2 + 2 * slot] = a_row; }
+			if (!REV) S.fb[pd.res_off + a_row] = -2;
+		} else if (REV) finish_reverse(S, pd, a_row, next_min);
+		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
+	}
+}
+
+// rows whose NK ranked candidates all fell inside the error margin (near-duplicate descriptors):
+// exact full scan, one wavefront per row -- lane l scans columns l, l+64, ... with the sequential
+// update of matcher.cc:42-48; the lane states are merged so that the result is the one a single
+// ascending scan produces (first index on equal minima, second-smallest as a multiset).
+template <bool REV>
+__global__ void __launch_bounds__(64) k_match_slow(MatchState S) {
+	const int* q = REV ? S.slow_rev : S.slow_fwd;
+	int n = q[0]; n = n < S.slow_cap ? n : S.slow_cap;
+	const int lane = threadIdx.x;
+	for (int i = blockIdx.x; i < n; i += gridDim.x) {
+		const int pair = q[1 + 2 * i], a = q[2 + 2 * i];
+		const PairDesc pd = S.pairs[pair];
+		const float* A = S.desc + (long long)pd.a_off * 128;
+		const float* B = S.desc + (long long)pd.b_off * 128;
+		const float* x = REV ? B + (long long)S.fb[pd.res_off + a] * 128 : A + (long long)a * 128;
+		const float* Y = REV ? A : B;
+		const int ky = REV ? pd.ka : pd.kb;
+		float mn = FLT_MAX, next_min = FLT_MAX; int min_idx = 0x7fffffff;
+		for (int kk = lane; kk < ky; kk += 64) {
+			if (REV && kk == a) continue;
+			const float d = euclidean_sqr_exact(x, Y + (long long)kk * 128);
+			if (d < mn) { next_min = mn; mn = d; min_idx = kk; }
+			else if (d < next_min) next_min = d;
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			const float omn = __shfl_xor(mn, off), onx = __shfl_xor(next_min, off); const int oid = __shfl_xor(min_idx, off);
+			const bool mine = mn < omn || (mn == omn && min_idx < oid);
+			const float lo_next = mine ? next_min : onx, hi_min = mine ? omn : mn;
+			next_min = lo_next < hi_min ? lo_next : hi_min;
+			if (!mine) { mn = omn; min_idx = oid; }
+		}
+		if (lane == 0) {
+			if (!REV) finish_forward(S, pd, pair, a, mn, next_min, min_idx == 0x7fffffff ? -1 : min_idx);
+			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, a, next_min < f ? next_min : f); }
+		}
+	}
 }
 
 }	// namespace
@@ -245,81 +344,94 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 
 	std::vector<WorkItem> work;
 	std::vector<PairDesc> pds(npairs);
-	std::vector<int2> blocks;
-	long long top_rows = 0, res_rows = 0;
+	long long res_rows = 0;
 	for (int p = 0; p < npairs; ++p) {
 		const int i = pairs[2 * p], j = pairs[2 * p + 1];
 		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) { delete m; OP_FAIL(OP_ERR_INVALID, "op_match_pairs: image index out of range"); }
-		const int rev = fv.counts[i] > fv.counts[j];                       // matcher.cc:21
+		const int rev = fv.counts[i] > fv.counts[j];                       // matcher.cc:21: the smaller set queries
 		const int ia = rev ? j : i, ib = rev ? i : j;
 		PairDesc& pd = pds[p];
 		pd.a_off = (int)fv.offsets[ia]; pd.ka = fv.counts[ia];
 		pd.b_off = (int)fv.offsets[ib]; pd.kb = fv.counts[ib];
 		pd.rev = rev;
-		pd.topA_off = (int)top_rows; top_rows += pd.ka;
-		pd.topB_off = (int)top_rows; top_rows += pd.kb;
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
-		if (pd.ka > 0 && pd.kb > 0) {
-			for (int rb = 0; rb * 128 < pd.ka; ++rb) work.push_back({pd.a_off, pd.ka, pd.b_off, pd.kb, rb, pd.topA_off});
-			for (int rb = 0; rb * 128 < pd.kb; ++rb) work.push_back({pd.b_off, pd.kb, pd.a_off, pd.ka, rb, pd.topB_off});
-			for (int rb = 0; rb * 128 < pd.ka; ++rb) blocks.push_back(make_int2(p, rb));
-		}
+		if (pd.ka > 0 && pd.kb > 0)
+			for (int rb = 0; rb * 128 < pd.ka; ++rb) work.push_back({p, rb});
 	}
-	if (top_rows >= (1LL << 29)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: too many rows in one call; split the pair list"); }
+	if (res_rows >= (1LL << 30)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: too many rows in one call; split the pair list"); }
+	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
+	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
-	float *d_norms = nullptr, *d_top_s = nullptr; int *d_top_i = nullptr, *d_res = nullptr; unsigned* d_gmax = nullptr;
-	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr; int2* d_blocks = nullptr;
-	std::vector<int> h_res(std::max<long long>(res_rows, 1), -1);
+	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr;
+	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_res = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
+	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr;
+	std::vector<int> h_res(nres, -1);
 	int rc = OP_OK;
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
 	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
 	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
-	MCHK(pool_alloc((void**)&d_top_s, sizeof(float) * 4 * std::max<long long>(top_rows, 1)));
-	MCHK(pool_alloc((void**)&d_top_i, sizeof(int) * 4 * std::max<long long>(top_rows, 1)));
-	MCHK(pool_alloc((void**)&d_res, sizeof(int) * std::max<long long>(res_rows, 1)));
+	MCHK(pool_alloc((void**)&d_fmn, sizeof(float) * nres));
+	MCHK(pool_alloc((void**)&d_fnext, sizeof(float) * nres));
+	MCHK(pool_alloc((void**)&d_fb, sizeof(int) * nres));
+	MCHK(pool_alloc((void**)&d_surv, sizeof(int) * nres));
+	MCHK(pool_alloc((void**)&d_nsurv, sizeof(int) * npairs));
+	MCHK(pool_alloc((void**)&d_res, sizeof(int) * nres));
+	MCHK(pool_alloc((void**)&d_slow, sizeof(int) * 2 * (1 + 2 * (size_t)slow_cap)));
 	MCHK(pool_alloc((void**)&d_work, sizeof(WorkItem) * std::max<size_t>(work.size(), 1)));
 	MCHK(pool_alloc((void**)&d_pds, sizeof(PairDesc) * npairs));
-	MCHK(pool_alloc((void**)&d_blocks, sizeof(int2) * std::max<size_t>(blocks.size(), 1)));
 	MCHK(hipMemsetAsync(d_gmax, 0, sizeof(unsigned), st));
-	MCHK(hipMemsetAsync(d_res, 0xff, sizeof(int) * std::max<long long>(res_rows, 1), st));
+	MCHK(hipMemsetAsync(d_nsurv, 0, sizeof(int) * npairs, st));
+	MCHK(hipMemsetAsync(d_res, 0xff, sizeof(int) * nres, st));
+	MCHK(hipMemsetAsync(d_slow, 0, sizeof(int), st));
+	MCHK(hipMemsetAsync(d_slow + 1 + 2 * (size_t)slow_cap, 0, sizeof(int), st));
 	if (!work.empty()) MCHK(hipMemcpyAsync(d_work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
 	MCHK(hipMemcpyAsync(d_pds, pds.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice, st));
-	if (!blocks.empty()) MCHK(hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
 	{
 		ProfScope ps(ctx, "matcher norms");
 		hipLaunchKernelGGL(k_norms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, fv.desc, total, d_norms, d_gmax);
 		MCHK(hipGetLastError());
 	}
 	if (!work.empty()) {
-		ProfScope ps(ctx, "matcher mfma top4");
-		hipLaunchKernelGGL(k_match_top4, dim3((unsigned)work.size()), dim3(256), 0, st, fv.desc, d_norms, d_work, d_top_s, d_top_i);
-		MCHK(hipGetLastError());
+		MatchState S;
+		S.desc = fv.desc; S.norms = d_norms; S.gmax_bits = d_gmax; S.pairs = d_pds;
+		S.fb = d_fb; S.fmn = d_fmn; S.fnext = d_fnext; S.surv = d_surv; S.nsurv = d_nsurv; S.res = d_res;
+		S.slow_fwd = d_slow; S.slow_rev = d_slow + 1 + 2 * (size_t)slow_cap; S.slow_cap = slow_cap;
+		S.rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
+		{
+			ProfScope ps(ctx, "matcher mfma forward");
+			hipLaunchKernelGGL(k_match_sweep<false>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
+			MCHK(hipGetLastError());
+			hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(64), 0, st, S);
+			MCHK(hipGetLastError());
+		}
+		{
+			// the reverse strip: same work list; row blocks beyond a pair's survivor count exit at once
+			ProfScope ps(ctx, "matcher mfma reverse");
+			hipLaunchKernelGGL(k_match_sweep<true>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
+			MCHK(hipGetLastError());
+			hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(64), 0, st, S);
+			MCHK(hipGetLastError());
+		}
 	}
-	if (!blocks.empty()) {
-		ProfScope ps(ctx, "matcher decide");
-		const float rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
-		hipLaunchKernelGGL(k_match_decide, dim3((unsigned)blocks.size()), dim3(128), 0, st, fv.desc, d_norms, d_gmax, d_pds, d_blocks,
-				d_top_s, d_top_i, rr, d_res);
-		MCHK(hipGetLastError());
-	}
-	MCHK(hipMemcpyAsync(h_res.data(), d_res, sizeof(int) * std::max<long long>(res_rows, 1), hipMemcpyDeviceToHost, st));
+	MCHK(hipMemcpyAsync(h_res.data(), d_res, sizeof(int) * nres, hipMemcpyDeviceToHost, st));
 	MCHK(hipStreamSynchronize(st));
 	resolve_profile(ctx);
 	for (int p = 0; p < npairs; ++p) {
 		const PairDesc& pd = pds[p];
-		std::vector<std::pair<int, int>> v;
-		for (int a = 0; a < pd.ka; ++a) {
-			const int b = h_res[pd.res_off + a];
-			if (b >= 0) v.push_back(pd.rev ? std::make_pair(b, a) : std::make_pair(a, b));   // matcher.cc:68-69
+		std::vector<int>& v = m->pairs[p];
+		if (!pd.rev) {                       // rows ascend in a: already sorted by (first, second)
+			for (int a = 0; a < pd.ka; ++a) { const int b = h_res[pd.res_off + a]; if (b >= 0) { v.push_back(a); v.push_back(b); } }
+		} else {                             // pairs are <b, a> (matcher.cc:68-69): sort by b
+			std::vector<std::pair<int, int>> t;
+			for (int a = 0; a < pd.ka; ++a) { const int b = h_res[pd.res_off + a]; if (b >= 0) t.emplace_back(b, a); }
+			std::sort(t.begin(), t.end());
+			for (auto& q : t) { v.push_back(q.first); v.push_back(q.second); }
 		}
-		std::sort(v.begin(), v.end());
-		m->pairs[p].reserve(v.size() * 2);
-		for (auto& q : v) { m->pairs[p].push_back(q.first); m->pairs[p].push_back(q.second); }
-		m->total += (int64_t)v.size();
+		m->total += (int64_t)(v.size() / 2);
 	}
 done:
-	pool_free(d_norms); pool_free(d_gmax); pool_free(d_top_s); pool_free(d_top_i);
-	pool_free(d_res); pool_free(d_work); pool_free(d_pds); pool_free(d_blocks);
+	pool_free(d_norms); pool_free(d_gmax); pool_free(d_fmn); pool_free(d_fnext); pool_free(d_fb); pool_free(d_surv);
+	pool_free(d_nsurv); pool_free(d_res); pool_free(d_slow); pool_free(d_work); pool_free(d_pds);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
 	*out = m;
