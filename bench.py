@@ -73,6 +73,45 @@ def cpu_baseline(cfg, views, log):
     }
 
 
+def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
+    """ConnectedImages::blend of the rank's images under the homographies of a 2-row camera sweep
+    (spherical projection, ESTIMATE_CAMERA mode): LinearBlender as the default config selects
+    (MULTIBAND 0) and MultiBandBlender(5).  Inputs resident in HBM; the canvas stays in HBM."""
+    from openpano_amd.config import PanoConfig
+    n = len(inputs)
+    cols = -(-n // 2)
+    f = 3.2 * W
+    homos = []
+    for i in range(n):
+        r, c = divmod(i, cols)
+        yaw = (c - cols / 2) * 0.55 * W / f; pitch = (r - 0.5) * 0.55 * H / f
+        Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(pitch), np.sin(pitch)], [0, -np.sin(pitch), np.cos(pitch)]])
+        homos.append(Ry @ Rx @ np.diag([1.0 / f, 1.0 / f, 1.0]))
+    homos = np.stack(homos)
+    res = {}
+    for key, over in (("linear", dict(MULTIBAND=0)), ("multiband5", dict(MULTIBAND=5))):
+        bcfg = PanoConfig(**over)
+        cv = hip.blend(ctx, bcfg, inputs, homos, 2, n // 2); cv.free()          # warm-up
+        ctx.set_profiling(True); ctx.profile_reset()
+        steps = max(1, min(args.steps, 5))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            cv = hip.blend(ctx, bcfg, inputs, homos, 2, n // 2)
+            hw = (cv.h, cv.w); cv.free()
+        torch.cuda.synchronize(); t = time.perf_counter() - t0
+        prof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith(("blend", "multiband"))}
+        ctx.set_profiling(False)
+        alg = 12.0 * H * W * n + 12.0 * hw[0] * hw[1]            # SURVEY 8(d): every source pixel once + canvas write
+        kms = sum(prof.values())
+        res[key] = {"ms_per_blend": t / steps * 1e3, "canvas": [hw[0], hw[1]], "output_mpix_per_s": hw[0] * hw[1] * steps / t / 1e6,
+                    "stage_ms": {k: round(v, 4) for k, v in prof.items()},
+                    "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else None, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else None,
+                                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kms}}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +120,7 @@ def main():
     ap.add_argument("--images", type=int, default=38, help="images per rank (BASELINE config 4: 38)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-blend", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,10 +243,17 @@ def main():
                                "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": b_path},
     }
 
-    # ---------------- all-pairs match loop ----------------
+    # ---------------- all-pairs match loop (+ RANSAC at N=1) ----------------
+    args.H, args.W = H, W
     if hasattr(hip, "match_pairs") and not args.no_match:
         from bench_match import run_match_loop
         out["match"] = run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, log)
+        if out["match"].get("ransac") is not None:
+            out["ransac"] = out["match"].pop("ransac")
+
+    # ---------------- final warp + blend of this rank's images (N=1 only: rank 0 renders) ----------------
+    if world == 1 and not args.no_blend:
+        out["blend"] = run_blend(hip, ctx, cfg, inputs, H, W, args, log)
 
     # ---------------- CPU baseline (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

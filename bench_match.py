@@ -36,14 +36,15 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
     from openpano_amd.distributed import partition_pairs
     mine = partition_pairs(pairs, rank, world, all_counts if world > 1 else None)
     flops = sum(2.0 * 128 * all_counts[i] * all_counts[j] for i, j in mine)
-    m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up
+    m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up (and the match count)
     nmatch = sum(len(x) for x in m)
     ctx.set_profiling(True); ctx.profile_reset()
     steps = max(1, min(args.steps, 10))
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        hip.match_pairs(ctx, cfg, gfeats, mine)
+        mh = hip.match_pairs_handle(ctx, cfg, gfeats, mine)         # results stay in the op_matches handle
+        mh.free()
     barrier()
     t = time.perf_counter() - t0
     prof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith("matcher")}
@@ -68,6 +69,23 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
         res["roofline"] = {"kernel": "matcher mfma forward + reverse", "bound": "mfma", "achieved": ach, "peak": 157.3,
                            "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                            "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms}
+    # ---- RANSAC over the same pairs (batched TransformEstimation::get_transform + acceptance) ----
+    if world == 1:
+        shapes = [(args.W, args.H)] * nglob
+        mh = hip.match_pairs_handle(ctx, cfg, gfeats, mine)
+        ok, inl = hip.ransac_pairs_summary(ctx, cfg, gfeats, mh, mine, shapes, base_seed=1)     # warm-up
+        rsteps = max(1, min(args.steps, 5))
+        ctx.set_profiling(True); ctx.profile_reset()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(rsteps):
+            hip.ransac_pairs_summary(ctx, cfg, gfeats, mh, mine, shapes, base_seed=1)
+        torch.cuda.synchronize(); tr = time.perf_counter() - t0
+        rprof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith("ransac")}
+        ctx.set_profiling(False)
+        mh.free()
+        res["ransac"] = {"image_pairs_per_s": len(mine) * rsteps / tr, "ms_per_step": tr / rsteps * 1e3, "pairs": len(mine),
+                         "accepted_pairs": ok, "inliers": inl, "iterations": cfg.RANSAC_ITERATIONS,
+                         "stage_ms": {k: round(v, 4) for k, v in rprof.items()}}
     if gfeats is not feats:
         gfeats.free()
     return res

@@ -343,7 +343,7 @@ void cyl_proj(const CylProj& P, double px, double py, double out[2]) {       // 
 	out[1] = (py - P.cy) / (std::hypot(px - P.cx, (double)P.r));
 }
 
-struct Freer { std::vector<void*> v; ~Freer() { for (void* p : v) if (p) hipFree(p); } };
+struct Freer { std::vector<void*> v; ~Freer() { for (void* p : v) pool_free(p); } };
 
 }	// namespace
 
@@ -440,7 +440,7 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		if (s.on_device) b.data = s.data;
 		else {
 			float* d = nullptr;
-			HIPCHK(hipMalloc(&d, sizeof(float) * 3 * (size_t)s.h * s.w)); fr.v.push_back(d);
+			HIPCHK(pool_alloc((void**)&d, sizeof(float) * 3 * (size_t)s.h * s.w)); fr.v.push_back(d);
 			HIPCHK(hipMemcpyAsync(d, s.data, sizeof(float) * 3 * (size_t)s.h * s.w, hipMemcpyHostToDevice, st));
 			b.data = d;
 		}
@@ -453,15 +453,15 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		max_roi = std::max(max_roi, (long long)b.rw * b.rh);
 	}
 	BlendImg* d_imgs = nullptr;
-	HIPCHK(hipMalloc(&d_imgs, sizeof(BlendImg) * n)); fr.v.push_back(d_imgs);
+	HIPCHK(pool_alloc((void**)&d_imgs, sizeof(BlendImg) * n)); fr.v.push_back(d_imgs);
 	HIPCHK(hipMemcpyAsync(d_imgs, h_imgs.data(), sizeof(BlendImg) * n, hipMemcpyHostToDevice, st));
 	op_canvas* cv = new op_canvas;
 	cv->h = H; cv->w = W; cv->device = ctx->device;
-	if (hipMalloc(&cv->data, sizeof(float) * 3 * (size_t)H * W) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_blend: canvas allocation failed"); }
+	if (pool_alloc((void**)&cv->data, sizeof(float) * 3 * (size_t)H * W) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_blend: canvas allocation failed"); }
 	const BlendGeom bg{g->proj_method, g->proj_min[0], g->proj_min[1], g->resolution[0], g->resolution[1]};
 	const dim3 cgrid((W + 63) / 64, (H + 3) / 4);
 #define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
-	hipFree(cv->data); delete cv; return OP_ERR_HIP; } } while (0)
+	pool_free(cv->data); delete cv; return OP_ERR_HIP; } } while (0)
 	if (cfg->MULTIBAND <= 0) {
 		ProfScope ps(ctx, "blend linear");
 		hipLaunchKernelGGL(k_blend_linear, cgrid, dim3(256), 0, st, bg, d_imgs, n, cv->data, H, W, cfg->ORDERED_INPUT, cfg->LAZY_READ);
@@ -469,11 +469,11 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 	} else {
 		const int L = cfg->MULTIBAND;
 		float4 *cur = nullptr, *nxt = nullptr, *tmp = nullptr; unsigned char *mask = nullptr, *tmask = nullptr;
-		BCHK(hipMalloc(&cur, sizeof(float4) * roi_total)); fr.v.push_back(cur);
-		BCHK(hipMalloc(&nxt, sizeof(float4) * roi_total)); fr.v.push_back(nxt);
-		BCHK(hipMalloc(&tmp, sizeof(float4) * roi_total)); fr.v.push_back(tmp);
-		BCHK(hipMalloc(&mask, roi_total)); fr.v.push_back(mask);
-		BCHK(hipMalloc(&tmask, (size_t)H * W)); fr.v.push_back(tmask);
+		BCHK(pool_alloc((void**)&cur, sizeof(float4) * roi_total)); fr.v.push_back(cur);
+		BCHK(pool_alloc((void**)&nxt, sizeof(float4) * roi_total)); fr.v.push_back(nxt);
+		BCHK(pool_alloc((void**)&tmp, sizeof(float4) * roi_total)); fr.v.push_back(tmp);
+		BCHK(pool_alloc((void**)&mask, roi_total)); fr.v.push_back(mask);
+		BCHK(pool_alloc((void**)&tmask, (size_t)H * W)); fr.v.push_back(tmask);
 		BCHK(hipMemsetAsync(tmask, 0, (size_t)H * W, st));
 		const dim3 rgrid((unsigned)((max_roi + 255) / 256), n);
 		{ ProfScope ps(ctx, "multiband first level");
@@ -490,7 +490,7 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 				ProfScope ps(ctx, "multiband blur");
 				BlurTaps taps; memset(&taps, 0, sizeof(taps));
 				if (gauss_taps((float)(std::sqrt(level * 2 + 1.0) * 4), cfg->GAUSS_WINDOW_FACTOR, taps) != 0) {
-					hipFree(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
+					pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
 				}
 				hipLaunchKernelGGL(k_mb_blur<true>, rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
 				BCHK(hipGetLastError());
@@ -525,7 +525,7 @@ int op_canvas_copy(op_ctx* ctx, const op_canvas* c, float* host) {
 void op_canvas_free(op_canvas* c) {
 	if (!c) return;
 	hipSetDevice(c->device);
-	if (c->data) hipFree(c->data);
+	pool_free(c->data);
 	delete c;
 }
 
@@ -572,20 +572,20 @@ int op_cyl_warp(op_ctx* ctx, const op_config* cfg, const op_image* img, double h
 	const float* src = img->data;
 	if (!img->on_device) {
 		float* d = nullptr;
-		HIPCHK(hipMalloc(&d, sizeof(float) * 3 * (size_t)img->h * img->w)); fr.v.push_back(d);
+		HIPCHK(pool_alloc((void**)&d, sizeof(float) * 3 * (size_t)img->h * img->w)); fr.v.push_back(d);
 		HIPCHK(hipMemcpyAsync(d, img->data, sizeof(float) * 3 * (size_t)img->h * img->w, hipMemcpyHostToDevice, st));
 		src = d;
 	}
 	const CylProj P = cyl_projector(img->w, img->h, h_factor, cfg->FOCAL_LENGTH);
 	op_canvas* cv = new op_canvas;
 	cv->h = nh; cv->w = nw; cv->device = ctx->device;
-	if (hipMalloc(&cv->data, sizeof(float) * 3 * (size_t)nh * nw) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_cyl_warp: allocation failed"); }
+	if (pool_alloc((void**)&cv->data, sizeof(float) * 3 * (size_t)nh * nw) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_cyl_warp: allocation failed"); }
 	const CylParams cp{P.cx, P.cy, off[0], off[1], 1.0 / P.sizefactor, P.r};
 	{ ProfScope ps(ctx, "cylinder warp");
 	  hipLaunchKernelGGL(k_cyl_project, dim3((nw + 63) / 64, (nh + 3) / 4), dim3(256), 0, st, cp, src, img->h, img->w, cv->data, nh, nw); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	if (e != hipSuccess) { hipFree(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_cyl_warp: ") + hipGetErrorString(e)); }
+	if (e != hipSuccess) { pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_cyl_warp: ") + hipGetErrorString(e)); }
 	resolve_profile(ctx);
 	*out = cv;
 	return OP_OK;

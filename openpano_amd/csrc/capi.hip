@@ -22,6 +22,14 @@ ProfScope::~ProfScope() {
 	hipEventRecord(b, c->stream);
 	c->pending.push_back({stage, a, b});
 }
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+HostScope::HostScope(op_ctx* ctx, const char* l): c(ctx), label(l), t0(0) { if (c->profiling) t0 = now_ms(); }
+HostScope::~HostScope() {
+	if (!c->profiling) return;
+	const int st = c->prof_stage(label);
+	c->prof[st].total_ms += now_ms() - t0; c->prof[st].calls += 1;
+}
 void resolve_profile(op_ctx* c) {
 	for (auto& p : c->pending) {
 		float ms = 0;
@@ -29,6 +37,54 @@ void resolve_profile(op_ctx* c) {
 		c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
 	}
 	c->pending.clear();
+}
+
+// ---- host thread pool ----
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+namespace {
+struct HostPool {
+	std::vector<std::thread> th;
+	std::mutex mu; std::condition_variable cv_work, cv_done;
+	const std::function<void(int)>* body = nullptr;
+	std::atomic<int> next{0}; int n = 0; int active = 0; unsigned long gen = 0; bool stop = false;
+	std::mutex run_mu;      // one parallel loop at a time
+	HostPool() {
+		unsigned hw = std::thread::hardware_concurrency();
+		const int nt = (int)std::min<unsigned>(hw ? hw : 4, 32) - 1;
+		for (int i = 0; i < nt; ++i) th.emplace_back([this] { worker(); });
+	}
+	void drain() { for (int i; (i = next.fetch_add(1)) < n;) (*body)(i); }
+	void worker() {
+		unsigned long seen = 0;
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || gen != seen; });
+			if (stop) return;
+			seen = gen;
+			lk.unlock(); drain(); lk.lock();
+			if (--active == 0) cv_done.notify_all();
+		}
+	}
+	void run(int count, const std::function<void(int)>& f) {
+		std::lock_guard<std::mutex> rl(run_mu);
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			body = &f; n = count; next = 0; active = (int)th.size(); ++gen;
+		}
+		cv_work.notify_all();
+		drain();
+		std::unique_lock<std::mutex> lk(mu);
+		cv_done.wait(lk, [&] { return active == 0; });
+	}
+};
+HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }     // leaked: no join at exit
+}	// namespace
+void host_parallel_for(int n, const std::function<void(int)>& body) {
+	if (n <= 0) return;
+	if (n == 1) { body(0); return; }
+	host_pool().run(n, body);
 }
 
 // ---- device allocation cache ----
@@ -169,6 +225,7 @@ void op_ctx_destroy(op_ctx* c) {
 	pool_trim();
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+	if (c->pinned) hipHostFree(c->pinned);
 	if (c->owns_stream) hipStreamDestroy(c->stream);
 	delete c;
 }

@@ -29,6 +29,15 @@ struct op_ctx {
 	std::vector<hipEvent_t> ev_pool;                 // recycled events
 	struct Pending { int stage; hipEvent_t a, b; };
 	std::vector<Pending> pending;                    // recorded, not yet resolved
+	void* pinned = nullptr; size_t pinned_cap = 0;   // grow-only pinned host scratch for D2H results
+	void* pinned_scratch(size_t bytes) {
+		if (bytes <= pinned_cap) return pinned;
+		if (pinned) hipHostFree(pinned);
+		pinned = nullptr; pinned_cap = 0;
+		if (hipHostMalloc(&pinned, bytes + bytes / 4) != hipSuccess) return nullptr;
+		pinned_cap = bytes + bytes / 4;
+		return pinned;
+	}
 	int prof_stage(const std::string& label) {
 		for (size_t i = 0; i < prof.size(); ++i) if (prof[i].label == label) return (int)i;
 		prof.push_back(ProfStage{label, 0, 0});
@@ -42,6 +51,17 @@ struct ProfScope {
 	~ProfScope();
 };
 void resolve_profile(op_ctx* c);
+// host-side wall time of a stage, reported in the same table (labels end in " (host)")
+struct HostScope {
+	op_ctx* c; const char* label; double t0;
+	HostScope(op_ctx* ctx, const char* l);
+	~HostScope();
+};
+
+// Host-side parallel loop over [0, n): a persistent pool of std::threads (the process may host
+// several OpenMP runtimes -- PyTorch's, the reference's -- whose interplay cannot be relied on).
+#include <functional>
+void host_parallel_for(int n, const std::function<void(int)>& body);
 
 // Size-class cache of device allocations (per device, process-wide, thread-safe): result buffers
 // (op_features, op_canvas) and per-call temporaries come from here, so a steady-state call does

@@ -365,8 +365,9 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr;
 	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_res = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
 	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr;
-	std::vector<int> h_res(nres, -1);
+	int* h_res = (int*)ctx->pinned_scratch(sizeof(int) * nres);     // pinned: the D2H runs at link rate
 	int rc = OP_OK;
+	if (!h_res) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
 	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
 	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
@@ -413,7 +414,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 			MCHK(hipGetLastError());
 		}
 	}
-	MCHK(hipMemcpyAsync(h_res.data(), d_res, sizeof(int) * nres, hipMemcpyDeviceToHost, st));
+	MCHK(hipMemcpyAsync(h_res, d_res, sizeof(int) * nres, hipMemcpyDeviceToHost, st));
 	MCHK(hipStreamSynchronize(st));
 	resolve_profile(ctx);
 	for (int p = 0; p < npairs; ++p) {

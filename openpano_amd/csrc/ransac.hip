@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <omp.h>
 
 struct op_features;
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 	const double* P = pts + (long long)pa.pts_off * 4;
 	double H[9];
 	bool ok = false;
-	if (hyp < iters && pa.m >= pa.nsample) {
+	if (hyp < iters && pa.m >= pa.nsample && pa.m >= 8) {      // same gate as k_ransac_samples: otherwise no sample exists
 		const unsigned short* s = samples + pa.samp_off + (long long)hyp * 8;
 		int idx[8];
 #pragma unroll
@@ -78,8 +79,71 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 	if (hyp < iters) counts[(long long)blockIdx.y * iters + hyp] = ok ? cnt : -1;
 }
 
+// Sample tables: the std::mt19937 draw sequence of TransformEstimation::get_transform with its
+// rejection of repeated indices (transform_estimate.cc:64-77), one wavefront per pair.  The
+// generator state lives in LDS; the 64 lanes regenerate it (the three dependency phases of the
+// twist) and temper + reduce a whole block of 624 draws at once, lane 0 then consumes them in
+// order -- the stream position depends on the rejections, so consumption is sequential.
+__global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ seeds,
+		int iters, unsigned short* __restrict__ samples) {
+	__shared__ unsigned mt[624];
+	__shared__ unsigned short rd[624];
+	const PairArgs pa = pairs[blockIdx.x];
+	const int m = pa.m, ns = pa.nsample, lane = threadIdx.x;
+	if (m < 8 || m < ns) return;                       // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
+	if (lane == 0) {                                   // std::mt19937::seed
+		unsigned v = seeds[blockIdx.x]; mt[0] = v;
+		for (int i = 1; i < 624; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i; mt[i] = v; }
+	}
+	__syncthreads();
+	unsigned short* sp = samples + pa.samp_off;
+	int idx = 624;                                     // lane 0's position in the current block of draws
+	int sel[8]; int K = 0, t = 0;
+	while (K < iters) {                                // wave-uniform: K is broadcast after every block
+		// ---- twist (each phase reads only values the previous phases finished) ----
+		unsigned o0[4], o1[4];
+		for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i < 227) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
+		unsigned lastold = mt[623];
+		__syncthreads();
+		for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i < 227) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
+		__syncthreads();
+		// i in [227, 623): mt[i] = mt[i-227](new) ^ f(old[i], old[i+1]) ; chains of stride 227 are at most 2 long
+		for (int r = 0; r < 4; ++r) { const int i = 227 + lane + 64 * r; if (i < 454) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
+		__syncthreads();
+		for (int r = 0; r < 4; ++r) { const int i = 227 + lane + 64 * r; if (i < 454) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
+		__syncthreads();
+		for (int r = 0; r < 3; ++r) { const int i = 454 + lane + 64 * r; if (i < 623) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
+		__syncthreads();
+		for (int r = 0; r < 3; ++r) { const int i = 454 + lane + 64 * r; if (i < 623) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
+		__syncthreads();
+		if (lane == 0) { const unsigned y = (lastold & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+		__syncthreads();
+		// ---- temper + reduce all 624 draws ----
+		for (int i = lane; i < 624; i += 64) {
+			unsigned y = mt[i];
+			y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+			rd[i] = (unsigned short)(y % (unsigned)m);
+		}
+		__syncthreads();
+		// ---- lane 0 consumes the block in order (:70-77) ----
+		if (lane == 0) {
+			idx = 0;
+			while (idx < 624 && K < iters) {
+				const int r = rd[idx++];
+				bool dup = false;
+				for (int q = 0; q < t; ++q) dup |= (sel[q] == r);
+				if (dup) continue;
+				sel[t] = r; sp[K * 8 + t] = (unsigned short)r;
+				if (++t == ns) { t = 0; ++K; }
+			}
+		}
+		K = __shfl(K, 0);
+	}
+}
+
 // first hypothesis with the maximal inlier count (update_max, transform_estimate.cc:82)
-__global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ counts, int iters, int2* __restrict__ best) {
+__global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ counts, int iters, int2* __restrict__ best,
+		const PairArgs* __restrict__ pairs, const unsigned short* __restrict__ samples, unsigned short* __restrict__ best_samp) {
 	__shared__ int s_cnt[256], s_idx[256];
 	const int* c = counts + (long long)blockIdx.x * iters;
 	int bc = -1, bi = -1;
@@ -94,6 +158,10 @@ __global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ cou
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) best[blockIdx.x] = make_int2(s_idx[0], s_cnt[0]);
+	if (threadIdx.x < 8) {     // the winner's sample, for the host epilogue
+		const int bi0 = s_idx[0];
+		best_samp[blockIdx.x * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[blockIdx.x].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
+	}
 }
 
 // ---------------- host epilogue: fill_inliers_to_matchinfo and its helpers ----------------
@@ -240,6 +308,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	const int iters = cfg->RANSAC_ITERATIONS;
 	if (iters <= 0 || iters > 65536) { delete R; OP_FAIL(OP_ERR_UNSUPPORTED, "RANSAC_ITERATIONS must be in [1, 65536]"); }
 
+	std::unique_ptr<HostScope> hs(new HostScope(ctx, "ransac gather points (host)"));
 	std::vector<double> coor((size_t)std::max<long long>(total, 1) * 2);
 	if (total) HIPCHK(hipMemcpyAsync(coor.data(), op_features_coor_device(f), sizeof(double) * 2 * total, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -269,62 +338,52 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		pa[p] = PairArgs{(int)pts_total, h.m, affine ? 1 : 0, nsample, (double)inlier_dist, (long long)p * iters * 8};
 		pts_total += h.m;
 	}
-	// sample tables: std::mt19937 draw sequence with rejection of repeats (:67-77)
-	std::vector<unsigned short> samples((size_t)npairs * iters * 8, 0);
-#pragma omp parallel for schedule(dynamic)
-	for (int p = 0; p < npairs; ++p) {
-		const int m = ph[p].m;
-		if (m < 8 || m < nsample) continue;             // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
-		opransac::MT19937 rng;
-		rng.seed(seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u));
-		unsigned short* sp = samples.data() + (size_t)p * iters * 8;
-		for (int K = 0; K < iters; ++K) {
-			int sel[8];
-			for (int t = 0; t < nsample; ++t) {
-				int r; bool dup;
-				do {
-					r = (int)(rng.next() % (unsigned)m);
-					dup = false;
-					for (int q = 0; q < t; ++q) dup |= (sel[q] == r);
-				} while (dup);
-				sel[t] = r; sp[K * 8 + t] = (unsigned short)r;
-			}
-		}
-	}
+		// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
+	std::vector<unsigned> h_seeds(npairs);
+	for (int p = 0; p < npairs; ++p) h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
 	std::vector<double> pts_flat((size_t)std::max<long long>(pts_total, 1) * 4);
 	for (int p = 0; p < npairs; ++p) if (ph[p].m) std::memcpy(pts_flat.data() + (size_t)pa[p].pts_off * 4, ph[p].pts.data(), sizeof(double) * 4 * ph[p].m);
 
+	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
 	PairArgs* d_pa = nullptr; double* d_pts = nullptr; unsigned short* d_samp = nullptr; int* d_counts = nullptr; int2* d_best = nullptr;
+	unsigned* d_seeds = nullptr; unsigned short* d_bsamp = nullptr;
 	std::vector<int2> best(npairs);
+	std::vector<unsigned short> best_samp((size_t)npairs * 8);
 	int rc = OP_OK;
 #define RCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
-	RCHK(hipMalloc(&d_pa, sizeof(PairArgs) * npairs));
-	RCHK(hipMalloc(&d_pts, sizeof(double) * pts_flat.size()));
-	RCHK(hipMalloc(&d_samp, sizeof(unsigned short) * samples.size()));
-	RCHK(hipMalloc(&d_counts, sizeof(int) * (size_t)npairs * iters));
-	RCHK(hipMalloc(&d_best, sizeof(int2) * npairs));
+	RCHK(pool_alloc((void**)&d_pa, sizeof(PairArgs) * npairs));
+	RCHK(pool_alloc((void**)&d_pts, sizeof(double) * pts_flat.size()));
+	RCHK(pool_alloc((void**)&d_samp, sizeof(unsigned short) * (size_t)npairs * iters * 8));
+	RCHK(pool_alloc((void**)&d_seeds, sizeof(unsigned) * npairs));
+	RCHK(pool_alloc((void**)&d_bsamp, sizeof(unsigned short) * 8 * npairs));
+	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
+	RCHK(pool_alloc((void**)&d_counts, sizeof(int) * (size_t)npairs * iters));
+	RCHK(pool_alloc((void**)&d_best, sizeof(int2) * npairs));
 	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
 	RCHK(hipMemcpyAsync(d_pts, pts_flat.data(), sizeof(double) * pts_flat.size(), hipMemcpyHostToDevice, st));
-	RCHK(hipMemcpyAsync(d_samp, samples.data(), sizeof(unsigned short) * samples.size(), hipMemcpyHostToDevice, st));
 	{
-		ProfScope ps(ctx, "get_transform");
+		{ ProfScope ps2(ctx, "ransac mt19937 samples");
+		  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(64), 0, st, d_pa, d_seeds, iters, d_samp);
+		  RCHK(hipGetLastError()); }
+		ProfScope ps(ctx, "ransac hypotheses");
 		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, npairs), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts);
 		RCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_ransac_best, dim3(npairs), dim3(256), 0, st, d_counts, iters, d_best);
+		hipLaunchKernelGGL(k_ransac_best, dim3(npairs), dim3(256), 0, st, d_counts, iters, d_best, d_pa, d_samp, d_bsamp);
 		RCHK(hipGetLastError());
 	}
 	RCHK(hipMemcpyAsync(best.data(), d_best, sizeof(int2) * npairs, hipMemcpyDeviceToHost, st));
+	RCHK(hipMemcpyAsync(best_samp.data(), d_bsamp, sizeof(unsigned short) * 8 * npairs, hipMemcpyDeviceToHost, st));
 	RCHK(hipStreamSynchronize(st));
 	resolve_profile(ctx);
+	hs.reset(); hs.reset(new HostScope(ctx, "ransac acceptance epilogue (host)"));
 
 	// ---- host epilogue per pair (transform_estimate.cc:85-86, 150-218) ----
-#pragma omp parallel for schedule(dynamic)
-	for (int p = 0; p < npairs; ++p) {
+	host_parallel_for(npairs, [&](int p) {
 		op_ransac_result::Item& it = R->items[p];
 		const PairHost& h = ph[p];
 		it.best_hyp = best[p].x; it.best_count = best[p].y;
-		if (h.m < 8 || h.m < nsample || best[p].x < 0 || best[p].y < 0) continue;     // get_transform -> false
-		const unsigned short* sp = samples.data() + (size_t)p * iters * 8 + (size_t)best[p].x * 8;
+		if (h.m < 8 || h.m < nsample || best[p].x < 0 || best[p].y < 0) return;     // get_transform -> false
+		const unsigned short* sp = best_samp.data() + (size_t)p * 8;
 		const double* P = h.pts.data();
 		double Hb[9];
 		opransac::calc_transform(nsample, [&](int q) { return P2{P[4 * sp[q]], P[4 * sp[q] + 1]}; },
@@ -335,11 +394,11 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 			if (opransac::is_inlier(Hb, P2{P[4 * k], P[4 * k + 1]}, P2{P[4 * k + 2], P[4 * k + 3]}, inlier_dist)) inl.push_back(k);
 		it.confidence = -(float)inl.size();                                           // :153
 		it.inliers = inl;
-		if (inl.size() < 8) continue;                                                 // :154
+		if (inl.size() < 8) return;                                                 // :154
 		double homo[9], inv[9];
 		opransac::calc_transform((int)inl.size(), [&](int q) { return P2{P[4 * inl[q]], P[4 * inl[q] + 1]}; },
 				[&](int q) { return P2{P[4 * inl[q] + 2], P[4 * inl[q] + 3]}; }, affine, homo);   // :179
-		if (!inverse3(homo, inv)) continue;                                           // :182-184
+		if (!inverse3(homo, inv)) return;                                           // :182-184
 		auto match_cnt = [&](const std::vector<P2>& poly, bool first) {
 			if (poly.size() < 3) return 0;
 			PointInPolygon pip(poly);
@@ -359,24 +418,25 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		bool valid = true;
 		std::vector<P2> overlap = overlap_region(h.s1, h.s2, homo, inv);
 		const float r1m = inl.size() * 1.0f / match_cnt(overlap, true);
-		if (r1m < cfg->INLIER_IN_MATCH_RATIO) continue;
+		if (r1m < cfg->INLIER_IN_MATCH_RATIO) return;
 		const float r1p = inl.size() * 1.0f / keypoint_cnt(overlap, true, valid);
-		if (!valid || r1p < 0.01 || r1p > 1) continue;
+		if (!valid || r1p < 0.01 || r1p > 1) return;
 		overlap = overlap_region(h.s2, h.s1, inv, homo);
 		const float r2m = inl.size() * 1.0f / match_cnt(overlap, false);
-		if (r2m < cfg->INLIER_IN_MATCH_RATIO) continue;
+		if (r2m < cfg->INLIER_IN_MATCH_RATIO) return;
 		const float r2p = inl.size() * 1.0f / keypoint_cnt(overlap, false, valid);
-		if (!valid || r2p < 0.01 || r2p > 1) continue;
+		if (!valid || r2p < 0.01 || r2p > 1) return;
 		it.confidence = (float)((r1p + r2p) * 0.5);                                   // :200
-		if (it.confidence < cfg->INLIER_IN_POINTS_RATIO) continue;
+		if (it.confidence < cfg->INLIER_IN_POINTS_RATIO) return;
 		const double area = polygon_area(overlap);
 		const double area1 = (double)(h.s1.w * h.s1.h), area2 = (double)(h.s2.w * h.s2.h);
-		if (area / std::max(area1, area2) < 0.15) continue;
+		if (area / std::max(area1, area2) < 0.15) return;
 		std::memcpy(it.homo, homo, sizeof(homo));
 		it.ok = 1;
-	}
+	});
 done:
-	if (d_pa) hipFree(d_pa); if (d_pts) hipFree(d_pts); if (d_samp) hipFree(d_samp); if (d_counts) hipFree(d_counts); if (d_best) hipFree(d_best);
+	hs.reset();
+	pool_free(d_pa); pool_free(d_pts); pool_free(d_samp); pool_free(d_counts); pool_free(d_best); pool_free(d_seeds); pool_free(d_bsamp);
 #undef RCHK
 	if (rc != OP_OK) { delete R; return rc; }
 	*out = R;

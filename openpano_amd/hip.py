@@ -463,6 +463,23 @@ def ransac_pairs(ctx: Context, cfg, feats: Features, matches: Matches, pairs, sh
     return out
 
 
+def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0):
+    """op_ransac_pairs without unpacking every pair into Python: -> (accepted pairs, total inliers)."""
+    L = lib()
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
+                            sh.ctypes.data_as(C.c_void_p), None, int(base_seed), C.byref(h)))
+    ok = 0; inl = 0
+    for p in range(len(pr)):
+        if L.op_ransac_ok(h, p):
+            ok += 1; inl += L.op_ransac_inlier_count(h, p)
+    L.op_ransac_free(h)
+    return ok, inl
+
+
 def match_pairs(ctx: Context, cfg, feats: Features, pairs):
     """All requested image pairs in one call -> list of (M, 2) int32 arrays of
     <idx in image i, idx in image j>, sorted by (first, second) (``MatchData``, matcher.hh:14-25)."""

@@ -13,3 +13,10 @@ print("stage_ms", d["stage_ms"])
 m=d.get("match") or {}
 print("match ms/step", m.get("ms_per_step"), m.get("stage_ms"))
 PY
+python - <<PY
+import json
+d=json.load(open("gpurun_out/${tag}_bench.json"))
+print("ransac", d.get("ransac"))
+b=d.get("blend") or {}
+for k,v in b.items(): print("blend", k, v["ms_per_blend"], v["canvas"], v["stage_ms"], v["roofline"]["frac"])
+PY
