@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 		int iters, unsigned short* __restrict__ samples) {
 	__shared__ unsigned mt[624];
 	__shared__ unsigned short rd[624];
+	__shared__ unsigned short ob[624];
 	const PairArgs pa = pairs[blockIdx.x];
 	const int m = pa.m, ns = pa.nsample, lane = threadIdx.x;
 	if (m < 8 || m < ns) return;                       // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
@@ -97,9 +98,9 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 	}
 	__syncthreads();
 	unsigned short* sp = samples + pa.samp_off;
-	int idx = 624;                                     // lane 0's position in the current block of draws
-	int sel[8]; int K = 0, t = 0;
-	while (K < iters) {                                // wave-uniform: K is broadcast after every block
+	int vsel = -1;                                     // lane q < t: q-th index of the sample being drawn, else -1
+	int K = 0, t = 0, accepted = 0;
+	while (K < iters) {                                // K, t and the sample are wave-uniform
 		// ---- twist (each phase reads only values the previous phases finished) ----
 		unsigned o0[4], o1[4];
 		for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i < 227) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
@@ -125,19 +126,32 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 			rd[i] = (unsigned short)(y % (unsigned)m);
 		}
 		__syncthreads();
-		// ---- lane 0 consumes the block in order (:70-77) ----
-		if (lane == 0) {
-			idx = 0;
-			while (idx < 624 && K < iters) {
-				const int r = rd[idx++];
-				bool dup = false;
-				for (int q = 0; q < t; ++q) dup |= (sel[q] == r);
-				if (dup) continue;
-				sel[t] = r; sp[K * 8 + t] = (unsigned short)r;
-				if (++t == ns) { t = 0; ++K; }
+		// ---- consume the block in order (:70-77).  The automaton is sequential (the stream position
+		// depends on the rejections), so it runs on the scalar unit: 64 draws at a time sit in one
+		// VGPR across the lanes, v_readlane hands them out one by one, and the sample, its fill
+		// level and the counters are wave-uniform (SGPR) values; accepted draws are collected
+		// lane-wise and staged in LDS 64 at a time. ----
+		int cnt = 0, outv = 0;
+		for (int base = 0; base < 624 && K < iters; base += 64) {
+			const int v = base + lane < 624 ? (int)rd[base + lane] : 0;
+			const int lim = 624 - base < 64 ? 624 - base : 64;
+			for (int i = 0; i < lim && K < iters; ++i) {
+				const int r = __builtin_amdgcn_readlane(v, i);
+				if (__ballot(vsel == r) != 0ULL) continue;           // already selected (:73-75); lane q < t holds sel[q]
+				vsel = lane == t ? r : vsel;
+				if (lane == (cnt & 63)) outv = r;
+				++cnt;
+				if ((cnt & 63) == 0) ob[cnt - 64 + lane] = (unsigned short)outv;
+				if (++t == ns) { t = 0; ++K; vsel = -1; }
 			}
 		}
-		K = __shfl(K, 0);
+		if (lane < (cnt & 63)) ob[(cnt & ~63) + lane] = (unsigned short)outv;
+		__syncthreads();
+		for (int i = lane; i < cnt; i += 64) {           // accepted draw number -> (hypothesis, slot)
+			const int a = accepted + i;
+			sp[(a / ns) * 8 + a % ns] = ob[i];
+		}
+		accepted += cnt;
 	}
 }
 
