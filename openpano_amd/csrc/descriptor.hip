@@ -28,7 +28,7 @@ struct DescLds {
 	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
 	float hb[REC_CAP];               // hbind
 	float omh[REC_CAP];              // 1 - hbind
-	unsigned short list[16][LIST_CAP];   // entry = record | u << 9 | h0 << 11
+	__attribute__((aligned(16))) unsigned short list[16][LIST_CAP];   // entry = record | u << 9 | h0 << 11
 	int len[16];
 	float hist[128];
 };
@@ -77,19 +77,29 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			__syncthreads();
 			const int mylen = S.len[cell];
 			const unsigned short* mylist = S.list[cell];
-#pragma unroll 4
-			for (int t = 0; t < maxlen; ++t) {
-				if (t < mylen) {
-					const unsigned e = mylist[t];
-					const int ridx = e & 511, u = (e >> 9) & 3, h0 = (e >> 11) & 7;
-					const float wx = S.w[u][ridx];
+			// 8 list entries per step: one 16-byte LDS read for the entries, then their 16 operand
+			// reads back to back, then the 8 ordered additions.  Entries past the end of this
+			// cell's list are stale data: they are masked to a +0.0f contribution (exact).
+			for (int t0 = 0; t0 < maxlen; t0 += 8) {
+				const uint4 pk = *(const uint4*)(mylist + t0);
+				const unsigned e2[4] = {pk.x, pk.y, pk.z, pk.w};
+				float wx[8], fac[8]; int dd[8], hh[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const unsigned e = (e2[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+					const int ridx = e & (REC_CAP - 1), u = (e >> 9) & 3, h0 = (e >> 11) & 7;
 					const int d = (hj - h0) & 3;
-					const float factor = d ? S.hb[ridx] : S.omh[ridx];
-					const float v = wx * factor;               // sift.cc:63-64
-					const float c = d < 2 ? v : 0.f;           // + 0.0f is exact
-					const int hi = ((h0 + d) >> 2) & 1;        // bin hbinf%8 / (hbinf+1)%8 in upper half?
-					acc0 += hi ? 0.f : c;
-					acc1 += hi ? c : 0.f;
+					wx[k] = S.w[u][ridx];
+					fac[k] = d ? S.hb[ridx] : S.omh[ridx];
+					dd[k] = (t0 + k < mylen) ? d : 3;          // 3: contributes +0.0f
+					hh[k] = ((h0 + d) >> 2) & 1;                // bin hbinf%8 / (hbinf+1)%8 in the upper half?
+				}
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const float v = wx[k] * fac[k];             // sift.cc:63-64
+					const float c = dd[k] < 2 ? v : 0.f;        // + 0.0f is exact
+					acc0 += hh[k] ? 0.f : c;
+					acc1 += hh[k] ? c : 0.f;
 				}
 			}
 			__syncthreads();
