@@ -23,6 +23,7 @@ namespace {
 
 constexpr int REC_CAP = 256;         // records (surviving samples) buffered per flush
 constexpr int LIST_CAP = 128;        // entries per spatial-cell list per flush
+constexpr int QCAP = 128;            // survivor queue (power of two, >= 2 x 64)
 
 struct DescLds {
 	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
@@ -31,6 +32,8 @@ struct DescLds {
 	__attribute__((aligned(16))) unsigned short list[16][LIST_CAP];   // entry = record | u << 9 | h0 << 11
 	int len[16];
 	float hist[128];
+	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates
+	float q_xr[QCAP], q_yr[QCAP];
 };
 
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
@@ -65,6 +68,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 #pragma unroll
 		for (int c = 0; c < 16; ++c) len[c] = 0;
 		int maxlen = 0;
+		int qhead = 0, qn = 0;            // survivor queue state (wave-uniform)
 
 		auto flush = [&]() {
 			// phase 2: ordered accumulation from the cell lists
@@ -108,35 +112,18 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			for (int c = 0; c < 16; ++c) len[c] = 0;
 		};
 
-		for (int i0 = 0; i0 < nsamp; i0 += 64) {
-			// flush first if this round could overflow a buffer
+		// phases 1b + 1c on one dense batch of queued survivors (window order preserved)
+		auto process_batch = [&](int n) {
+			// flush first if this batch could overflow a buffer
 			if (nrec + 64 > REC_CAP || maxlen + 64 > LIST_CAP) flush();
-			// phase 1a: cheap tests
-			const int e = i0 + lane;
-			bool ok = false;
-			int xx = 0, yy = 0;
-			float x_rot = 0.f, y_rot = 0.f, xbin = 0.f, ybin = 0.f;
-			long long gi = 0;
-			if (e < nsamp) {
-				xx = e / side - radius; yy = e % side - radius;
-				const int nowx = kp.x + xx, nowy = kp.y + yy;
-				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
-					const float fxx = (float)xx, fyy = (float)yy;
-					if (!(fxx * fxx + fyy * fyy > fr2)) {
-						y_rot = ((float)(-xx) * sinort + fyy * cosort) / hist_w;
-						x_rot = (fxx * cosort + fyy * sinort) / hist_w;
-						ybin = (y_rot + 2.f) - 0.5f; xbin = (x_rot + 2.f) - 0.5f;
-						// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
-						ok = (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f);
-						gi = (long long)nowy * w + nowx;
-					}
-				}
-			}
-			// phase 1b: ordered compaction + the expensive per-sample work on survivors
-			const unsigned long long mask = __ballot(ok);
-			const int ridx = nrec + __popcll(mask & lt_mask);
+			const bool ok = lane < n;
+			const int qi = (qhead + lane) & (QCAP - 1);
+			const int ridx = nrec + lane;
 			int yb = -9, xb = -9, h0 = 0;
 			if (ok) {
+				const int gi = S.q_gi[qi];
+				const float x_rot = S.q_xr[qi], y_rot = S.q_yr[qi];
+				const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
 				const float gdy = g_img[gi + w] - g_img[gi - w];
 				const float gdx = g_img[gi + 1] - g_img[gi - 1];
 				const float now_mag = opdev::hypotf_glibc(gdx, gdy);
@@ -155,20 +142,54 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				S.w[2][ridx] = wy1 * (1 - xbind); S.w[3][ridx] = wy1 * xbind;
 				S.hb[ridx] = hbind; S.omh[ridx] = 1 - hbind;
 			}
-			nrec += __popcll(mask);
+			nrec += n;
 			// phase 1c: ordered per-cell lists
-			if (mask) {
 #pragma unroll
-				for (int c = 0; c < 16; ++c) {
-					const int dy = (c >> 2) - yb, dx = (c & 3) - xb;
-					const bool touch = ok && (unsigned)dy < 2u && (unsigned)dx < 2u;
-					const unsigned long long m = __ballot(touch);
-					if (touch) S.list[c][len[c] + __popcll(m & lt_mask)] = (unsigned short)(ridx | ((dy * 2 + dx) << 9) | (h0 << 11));
-					len[c] += __popcll(m);
-					maxlen = len[c] > maxlen ? len[c] : maxlen;
+			for (int c = 0; c < 16; ++c) {
+				const int dy = (c >> 2) - yb, dx = (c & 3) - xb;
+				const bool touch = ok && (unsigned)dy < 2u && (unsigned)dx < 2u;
+				const unsigned long long m = __ballot(touch);
+				if (touch) S.list[c][len[c] + __popcll(m & lt_mask)] = (unsigned short)(ridx | ((dy * 2 + dx) << 9) | (h0 << 11));
+				len[c] += __popcll(m);
+				maxlen = len[c] > maxlen ? len[c] : maxlen;
+			}
+			qhead = (qhead + n) & (QCAP - 1); qn -= n;
+		};
+
+		// phase 1a: window scan in the reference's order (xx outer, yy inner: sift.cc:110-113); the
+		// cheap tests run on all samples, survivors are queued in order and handed to the expensive
+		// phases 64 at a time, so those always run with full wavefronts
+		int qx = lane / side, qy = lane % side;          // sample e = i0 + lane  ->  (e / side, e % side)
+		for (int i0 = 0; i0 < nsamp; i0 += 64) {
+			bool ok = false;
+			float x_rot = 0.f, y_rot = 0.f;
+			int gi = 0;
+			if (i0 + lane < nsamp) {
+				const int xx = qx - radius, yy = qy - radius;
+				const int nowx = kp.x + xx, nowy = kp.y + yy;
+				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
+					const float fxx = (float)xx, fyy = (float)yy;
+					if (!(fxx * fxx + fyy * fyy > fr2)) {
+						y_rot = ((float)(-xx) * sinort + fyy * cosort) / hist_w;
+						x_rot = (fxx * cosort + fyy * sinort) / hist_w;
+						const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
+						// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
+						ok = (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f);
+						gi = nowy * w + nowx;
+					}
 				}
 			}
+			qy += 64;
+			while (qy >= side) { qy -= side; ++qx; }
+			const unsigned long long mask = __ballot(ok);
+			if (ok) {
+				const int qi = (qhead + qn + __popcll(mask & lt_mask)) & (QCAP - 1);
+				S.q_gi[qi] = gi; S.q_xr[qi] = x_rot; S.q_yr[qi] = y_rot;
+			}
+			qn += __popcll(mask);
+			if (qn >= 64) { __syncthreads(); process_batch(64); }
 		}
+		if (qn > 0) { __syncthreads(); process_batch(qn); }
 		flush();
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
