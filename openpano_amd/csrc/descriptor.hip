@@ -29,7 +29,8 @@ struct DescLds {
 	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
 	float hb[REC_CAP];               // hbind
 	float omh[REC_CAP];              // 1 - hbind
-	__attribute__((aligned(16))) unsigned short list[16][LIST_CAP];   // entry = record | u << 9 | h0 << 11
+	// entry = record | u << 9 | h0 << 11 ; row pitch LIST_CAP + 8: the 16 cells' 16-byte reads hit disjoint banks
+	__attribute__((aligned(16))) unsigned short list[16][LIST_CAP + 8];
 	int len[16];
 	float hist[128];
 	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates

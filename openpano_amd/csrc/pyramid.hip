@@ -120,15 +120,18 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 // themselves only ever exist in LDS (two ping-pong buffers).
 constexpr int TW = OP_PYR_TW, TH = OP_PYR_TH;
 constexpr int GR = TH + 2, GC = TW + 2;       // blurred region incl. the 1-px gradient halo
-constexpr int PG = GC + 1;                    // pitch of G buffers (odd: lanes along rows are conflict-free)
+constexpr int PG = TH == 16 ? 75 : GC + 1;    // pitch of G / DoG buffers: with RH = 6 the row pass's (row, strip) lanes hit 32 distinct banks
 constexpr int PV = GR + (GR % 2 == 0 ? 1 : 2);  // pitch of the transposed column-pass buffer (odd -> conflict-free)
 constexpr int NPX = TW * TH / 256;            // tile pixels owned by one thread (lx = tid & 63, ly = (tid >> 6) + 4 k)
 constexpr int NHALO = 2 * GC + 2 * TH;        // ring elements of the G / DoG region around the tile
 static_assert(TW == 64 && TH % 4 == 0 && NHALO <= 256, "tile shape");
 // register blocking of the separable passes: strips of RV rows (column pass) / RH columns (row pass)
 constexpr int RV = TH == 32 ? 12 : (TH == 24 ? 9 : 6);
-constexpr int RH = TH == 32 ? 10 : (TH == 24 ? 8 : 5);
+constexpr int RH = TH == 32 ? 10 : (TH == 24 ? 8 : 6);   // TH 16: RH * PV = 114 = 18 (mod 32): strips of 18 rows tile the banks
 static_assert(((GR + RV - 1) / RV) * (GC + 12) <= 256 && ((GC + RH - 1) / RH) * GR <= 256, "blocking must fit 256 threads at halo 6");
+
+// rows of the transposed column-pass buffer: NC used + padding for the row pass's tail strip
+__host__ __device__ constexpr int vt_rows(int halo) { return ((GC + RH - 1) / RH) * RH + 2 * halo; }
 
 // register-blocked passes for kernel half-width C (taps = 2C+1)
 template <int C, int RV>
@@ -143,7 +146,7 @@ __device__ __forceinline__ void vpass_blocked(const float* __restrict__ In, floa
 #pragma unroll
 	for (int i = 0; i < RV + 2 * C; ++i) {
 		int rr = r0 + i + (halo - C);           // In row of G row (r0 + i - C)
-		rr = rr < GR + 2 * halo ? rr : GR + 2 * halo - 1;   // tail strip over-reads stay in bounds
+		if (strips * RV != GR) rr = rr < GR + 2 * halo ? rr : GR + 2 * halo - 1;   // tail strip over-reads stay in bounds
 		win[i] = In[rr * pin + c];
 	}
 	float kw[2 * C + 1];
@@ -168,8 +171,7 @@ __device__ __forceinline__ void hpass_blocked(const float* __restrict__ VT, floa
 	float win[RH + 2 * C];
 #pragma unroll
 	for (int i = 0; i < RH + 2 * C; ++i) {
-		int cc = g0 + i + (halo - C);
-		cc = cc < NC ? cc : NC - 1;
+		const int cc = g0 + i + (halo - C);     // tail strip over-reads land in VT's padding rows
 		win[i] = VT[cc * PV + r];
 	}
 	float kw[2 * C + 1];
@@ -240,6 +242,9 @@ __device__ __forceinline__ bool is_raw_extremum(const float* __restrict__ Dm, co
 // layers and to HBM (the sub-pixel refinement reads it), the Gaussian value goes to HBM when its
 // gradients will be needed.  As soon as three consecutive DoG layers sit in LDS the middle one is
 // scanned for raw extrema (feature/extrema.cc:170-216) -- nothing is re-read from HBM.
+// HALO_CT > 0: halo known at compile time (6 for the shipped Gaussian bank: all index arithmetic is constant-folded);
+// HALO_CT == 0: any halo (p.halo).
+template <int HALO_CT>
 __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int img = blockIdx.y;
@@ -250,11 +255,11 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 	const int t = tile - od.tile_begin;
 	const int tx = t % od.tiles_x, ty = t / od.tiles_x;
 	const int x0 = tx * TW, y0 = ty * TH;
-	const int halo = p.halo;
+	const int halo = HALO_CT > 0 ? HALO_CT : p.halo;
 	const int NR = GR + 2 * halo, NC = GC + 2 * halo, pin = NC;
 	float* In = smem;                       // NR x NC
-	float* VT = In + NR * pin;              // NC x PV (column-pass result, transposed)
-	float* G = VT + NC * PV;                // GR x PG current Gaussian
+	float* VT = In + NR * pin;              // vt_rows x PV (column-pass result, transposed)
+	float* G = VT + vt_rows(halo) * PV;     // GR x PG current Gaussian
 	float* Dr = G + GR * PG;                // 3 x GR x PG ring of DoG layers
 	const int tid = threadIdx.x;
 	const int ns = p.nscale;
@@ -393,7 +398,7 @@ __global__ void k_debug_math(int which, const float* x, const float* y, int n, f
 
 size_t pyramid_lds_bytes(int halo) {
 	const int NR = GR + 2 * halo, NC = GC + 2 * halo;
-	return sizeof(float) * ((size_t)NR * NC + (size_t)NC * PV + 4 * (size_t)GR * PG);
+	return sizeof(float) * ((size_t)NR * NC + (size_t)vt_rows(halo) * PV + 4 * (size_t)GR * PG);
 }
 
 hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t st) {
@@ -412,12 +417,14 @@ hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, 
 	static bool attr_set = false;
 	size_t lds = pyramid_lds_bytes(p.halo);
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void*)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+		hipError_t e = hipFuncSetAttribute((const void*)k_pyramid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pyramid<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
 	dim3 grid(p.total_tiles, p.n);
-	hipLaunchKernelGGL(k_pyramid, grid, dim3(256), lds, st, p, raw, raw_count, cap);
+	if (p.halo == 6) hipLaunchKernelGGL(k_pyramid<6>, grid, dim3(256), lds, st, p, raw, raw_count, cap);
+	else hipLaunchKernelGGL(k_pyramid<0>, grid, dim3(256), lds, st, p, raw, raw_count, cap);
 	return hipGetLastError();
 }
 
