@@ -192,14 +192,16 @@ __device__ __forceinline__ unsigned long long kp_key(const KeyPoint& k) {
 		((unsigned long long)(unsigned)(k.y & 0xFFFFF) << 20) | (unsigned long long)(unsigned)(k.x & 0xFFFFF);
 }
 constexpr int SORT_CHUNK = 2048;
+constexpr int SORT_SPLIT = 8;              // lanes sharing one keypoint's rank scan
+constexpr int SORT_KEYS = 256 / SORT_SPLIT;
 __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const int* count, int cap, KeyPoint* out) {
 	__shared__ unsigned long long s_key[SORT_CHUNK];
 	const int img = blockIdx.y;
 	const int n = count[img];
-	if ((int)(blockIdx.x * 256) >= n) return;
+	if ((int)(blockIdx.x * SORT_KEYS) >= n) return;
 	const KeyPoint* a = in + (long long)img * cap;
 	KeyPoint* b = out + (long long)img * cap;
-	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int i = blockIdx.x * SORT_KEYS + threadIdx.x / SORT_SPLIT, sub = threadIdx.x % SORT_SPLIT;
 	const bool live = i < n;
 	KeyPoint me;
 	if (live) me = a[i];
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 		for (int j = threadIdx.x; j < cn; j += 256) s_key[j] = kp_key(a[cb + j]);
 		__syncthreads();
 		if (live) {
-			for (int j = 0; j < cn; ++j) {
+			for (int j = sub; j < cn; j += SORT_SPLIT) {      // the 8 lanes of a keypoint read 8 consecutive keys
 				const unsigned long long kj = s_key[j];
 				if (kj < mykey) ++rank;
 				else if (kj == mykey) {
@@ -225,7 +227,9 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 			}
 		}
 	}
-	if (live) { me.src = rank; b[rank] = me; }
+#pragma unroll
+	for (int off = 1; off < SORT_SPLIT; off <<= 1) rank += __shfl_xor(rank, off);
+	if (live && sub == 0) { me.src = rank; b[rank] = me; }
 }
 
 // ---- OrientationAssign::calc_dir (feature/orientation.cc:34-100): one wavefront per keypoint.
@@ -385,7 +389,7 @@ hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count
 
 hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
 		KeyPoint* out, hipStream_t st) {
-	hipLaunchKernelGGL(k_sort_refined, dim3((cap + 255) / 256, p.n), dim3(256), 0, st, in, count, cap, out);
+	hipLaunchKernelGGL(k_sort_refined, dim3((cap + SORT_KEYS - 1) / SORT_KEYS, p.n), dim3(256), 0, st, in, count, cap, out);
 	return hipGetLastError();
 }
 
