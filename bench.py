@@ -206,21 +206,25 @@ def main():
         "sift descriptor": (k_rank / nimg) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
         "orientation": (k_rank / nimg) * (8 * 16 * 16),
     }
-    roofline = None
-    if dominant is not None:
-        b = alg.get(dominant)
-        dur_s = stage_ms[dominant] * 1e-3
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+        except Exception:
+            pmc = {}
+
+    def stage_roofline(name):
+        b = alg.get(name)
+        dur_s = stage_ms[name] * 1e-3
         ach = (b * nimg / dur_s / 1e9) if b else None
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(dominant, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": b * nimg if b else None, "avg_launch_ms": stage_ms[dominant]}
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (ach / HBM_PEAK_GBS) if ach else None,
+                "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),      # rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE) * 1024
+                "algorithmic_bytes_per_launch": b * nimg if b else None, "avg_launch_ms": stage_ms[name]}
+
+    roofline = stage_roofline(dominant) if dominant is not None else None
+    stage_rooflines = {k: stage_roofline(k) for k in stage_ms if k in alg}
     # whole SIFT path against SURVEY 8(d): 12WH + 88P + G + 528K per image
     G = (k_rank / nimg) * 8 * (16 * 16 + 37 * 37)
     b_path = nimg * (12 * H * W + 88 * P + G + 528 * (k_rank / nimg))
@@ -239,6 +243,7 @@ def main():
                    "parallelism": f"images sharded {nimg}/GPU x {args.gpus}"},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "roofline": roofline,
+        "stage_rooflines": stage_rooflines,
         "sift_path_roofline": {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": b_path},
     }
