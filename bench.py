@@ -73,6 +73,27 @@ def cpu_baseline(cfg, views, log):
     }
 
 
+def run_ingest(hip, ctx, cfg, views, k_rank, args):
+    """SIFT over HOST-resident images (the reference hands over Mat32f in host RAM, stitcherbase.cc:16):
+    every call pays the H2D copies.  fp32 Mat32f (12 B/px) vs decoder bytes (3 B/px, converted on the
+    device like read_img) -- SURVEY 8(f).1.  Reported next to `value`, never as `value`."""
+    res = {}
+    u8 = [(v * 255 + 0.5).astype(np.uint8) for v in views]
+    f32 = [(v.astype(np.float64) / 255.0).astype(np.float32) for v in u8]
+    for key, imgs in (("host_fp32", f32), ("host_uint8", u8)):
+        pinned = [torch.from_numpy(x).pin_memory().numpy() for x in imgs]      # page-locked like a decoder's output pool
+        f = hip.sift_batch(ctx, cfg, pinned); k = int(f.total); f.free()
+        steps = max(1, min(args.steps, 5))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            f = hip.sift_batch(ctx, cfg, pinned); f.free()
+        torch.cuda.synchronize(); t = time.perf_counter() - t0
+        nbytes = sum(x.nbytes for x in imgs)
+        res[key] = {"ms_per_step": t / steps * 1e3, "keypoints_per_s": k * steps / t, "h2d_bytes_per_step": nbytes,
+                    "h2d_gb_per_s_floor": nbytes * steps / t / 1e9, "descriptors": k}
+    return res
+
+
 def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
     """ConnectedImages::blend of the rank's images under the homographies of a 2-row camera sweep
     (spherical projection, ESTIMATE_CAMERA mode): LinearBlender as the default config selects
@@ -121,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-blend", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,9 +153,11 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OPENPANO_FORCE_DIST"):     # FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -259,6 +283,10 @@ def main():
     # ---------------- final warp + blend of this rank's images (N=1 only: rank 0 renders) ----------------
     if world == 1 and not args.no_blend:
         out["blend"] = run_blend(hip, ctx, cfg, inputs, H, W, args, log)
+
+    # ---------------- host-fed ingest (PCIe inclusive; never `value`) ----------------
+    if world == 1 and not args.no_ingest:
+        out["ingest"] = run_ingest(hip, ctx, cfg, views, k_rank, args)
 
     # ---------------- CPU baseline (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

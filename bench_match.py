@@ -15,7 +15,7 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
     nloc = feats.num_images
     counts = [feats.count(i) for i in range(nloc)]
     gather_ms = None
-    if world > 1:
+    if dist is not None:
         from openpano_amd.distributed import allgather_descriptors
         total = int(feats.total)
         # zero-copy torch view of the library-owned descriptor buffer (same HIP runtime)
@@ -34,7 +34,7 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
         all_counts = counts
     pairs = [(i, j) for i in range(nglob) for j in range(i + 1, nglob)]
     from openpano_amd.distributed import partition_pairs
-    mine = partition_pairs(pairs, rank, world, all_counts if world > 1 else None)
+    mine = partition_pairs(pairs, rank, world, all_counts if dist is not None else None)
     flops = sum(2.0 * 128 * all_counts[i] * all_counts[j] for i, j in mine)
     m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up (and the match count)
     nmatch = sum(len(x) for x in m)

@@ -81,10 +81,14 @@ int op_ctx_profile_count(op_ctx* ctx);
 int op_ctx_profile_get(op_ctx* ctx, int i, const char** label, double* total_ms, long* calls);
 
 typedef struct op_image {
-	const float* data;   /* H x W x 3 fp32 */
+	const void* data;    /* H x W x 3, row-major interleaved RGB; element type per dtype */
 	int h, w;
 	int on_device;       /* 0: host pointer (copied H2D inside the call), 1: device pointer */
+	int dtype;           /* OP_F32 (0): fp32 in [0,1] = Mat32f ; OP_U8 (1): decoder bytes, converted on the
+	                      * device exactly like read_img does, (float)byte / 255.0 (lib/imgio.cc:54-56,75-77):
+	                      * a quarter of the PCIe / HBM traffic of the fp32 image */
 } op_image;
+enum { OP_F32 = 0, OP_U8 = 1 };
 
 /* =====================================================================================
  * SIFT  -- replaces FeatureDetector::detect_feature / SIFTDetector::do_detect_feature

@@ -569,7 +569,8 @@ int op_cyl_warp(op_ctx* ctx, const op_config* cfg, const op_image* img, double h
 	if (rc != OP_OK) return rc;
 	if (nw <= 0 || nh <= 0) OP_FAIL(OP_ERR_INVALID, "op_cyl_warp: empty output");
 	Freer fr;
-	const float* src = img->data;
+	if (img->dtype != OP_F32) OP_FAIL(OP_ERR_UNSUPPORTED, "op_cyl_warp: fp32 images only");
+	const float* src = (const float*)img->data;
 	if (!img->on_device) {
 		float* d = nullptr;
 		HIPCHK(pool_alloc((void**)&d, sizeof(float) * 3 * (size_t)img->h * img->w)); fr.v.push_back(d);

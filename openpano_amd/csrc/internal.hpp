@@ -96,7 +96,8 @@ struct SiftPlan {
 	long long ws_stride;        // floats per image workspace
 	float* ws;
 	float* work;                // n x wh x ww x 3 (only materialised for the staged dump)
-	const float* const* srcs;   // device array of n source pointers (device memory)
+	const void* const* srcs;    // device array of n source pointers (device memory)
+	int src_u8;                 // 0: fp32 sources, 1: uint8 sources (converted like read_img, lib/imgio.cc:54-56)
 	// Gaussian bank (feature/gaussian.cc:17-40): kern[s][center + k], s = 1..nscale-1
 	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
 	int kcenter[OP_MAX_SCALE];

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_norms(const float* desc, long long tota
 	float s = 0.f;
 	for (int t = 0; t < 32; ++t) { f32x4 v = p[t]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 	norms[i] = s;
-	atomicMax(gmax_bits, __float_as_uint(s));
+	if (s == s) atomicMax(gmax_bits, __float_as_uint(s));     // a NaN descriptor must not poison the margin of every row
 }
 
 // running top-NK (descending score); the common case is the single rejecting compare

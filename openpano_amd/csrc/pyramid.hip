@@ -41,12 +41,22 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
 constexpr int WT = 64, WR = 16;               // working-image tile
 constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 
+// one source tap: fp32 as is, or a decoder byte converted like read_img (lib/imgio.cc:54-56,75-77)
+__device__ __forceinline__ float src_tap(const float* s, long long i, const float*) { return s[i]; }
+__device__ __forceinline__ float src_tap(const unsigned char* s, long long i, const float* lut) { return lut[s[i]]; }
+
+template <typename SrcT>
 __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work) {
 	__shared__ float s_rgb[3][(WR + 1) * WP];
+	__shared__ float s_lut[256];
 	const int img = blockIdx.z;
 	const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WR;
 	const int tid = threadIdx.x;
-	const float* src = p.srcs[img];
+	const SrcT* src = (const SrcT*)p.srcs[img];
+	if (sizeof(SrcT) == 1) {      // (float)byte / 255.0: float -> double, IEEE division, round to float
+		s_lut[tid] = (float)((double)(float)tid / 255.0);
+		__syncthreads();
+	}
 	// working-image tile: lib/imgproc.cc:22-80 on the source
 	{
 		const float fx = (float)p.wh / (float)p.sh, fy = (float)p.ww / (float)p.sw;
@@ -60,11 +70,10 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 				resize_coord(row, ifx, p.sh, sx, rx);
 				resize_coord(col, ify, p.sw, sy, ry);
 				const float irx = 1.0f - rx, iry = 1.0f - ry;
-				const float* p0 = src + ((long long)sx * p.sw + sy) * 3;
-				const float* p1 = p0 + (long long)p.sw * 3;
-				v0 = bilerp(p0[0], p0[3], p1[0], p1[3], rx, irx, ry, iry);
-				v1 = bilerp(p0[1], p0[4], p1[1], p1[4], rx, irx, ry, iry);
-				v2 = bilerp(p0[2], p0[5], p1[2], p1[5], rx, irx, ry, iry);
+				const long long i0 = ((long long)sx * p.sw + sy) * 3, i1 = i0 + (long long)p.sw * 3;
+				v0 = bilerp(src_tap(src, i0, s_lut), src_tap(src, i0 + 3, s_lut), src_tap(src, i1, s_lut), src_tap(src, i1 + 3, s_lut), rx, irx, ry, iry);
+				v1 = bilerp(src_tap(src, i0 + 1, s_lut), src_tap(src, i0 + 4, s_lut), src_tap(src, i1 + 1, s_lut), src_tap(src, i1 + 4, s_lut), rx, irx, ry, iry);
+				v2 = bilerp(src_tap(src, i0 + 2, s_lut), src_tap(src, i0 + 5, s_lut), src_tap(src, i1 + 2, s_lut), src_tap(src, i1 + 5, s_lut), rx, irx, ry, iry);
 				if (write_work && r < WR && c < WT) {
 					float* dst = p.work + (((long long)img * p.wh + row) * p.ww + col) * 3;
 					dst[0] = v0; dst[1] = v1; dst[2] = v2;
@@ -403,7 +412,8 @@ size_t pyramid_lds_bytes(int halo) {
 
 hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t st) {
 	dim3 grid((p.ww + WT - 1) / WT, (p.wh + WR - 1) / WR, p.n);
-	hipLaunchKernelGGL(k_grey_octaves, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
+	if (p.src_u8) hipLaunchKernelGGL(k_grey_octaves<unsigned char>, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
+	else hipLaunchKernelGGL(k_grey_octaves<float>, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
 	return hipGetLastError();
 }
 

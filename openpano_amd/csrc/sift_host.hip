@@ -186,23 +186,26 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	plan.ws = (float*)W.ws.p; plan.work = (float*)W.work.p;
 
 	// --- sources: device pointers as they are, host images staged through one H2D copy each
+	plan.src_u8 = imgs[0]->dtype == OP_U8 ? 1 : 0;
+	const size_t img_bytes = (plan.src_u8 ? 1 : sizeof(float)) * (size_t)sh * sw * 3;
+	const size_t img_stride = (img_bytes + 255) & ~(size_t)255;
 	size_t host_bytes = 0;
-	for (auto* im : imgs) if (!im->on_device) host_bytes += sizeof(float) * (size_t)sh * sw * 3;
+	for (auto* im : imgs) if (!im->on_device) host_bytes += img_stride;
 	if (host_bytes) HIPCHK(W.staging.ensure(host_bytes));
 	{
-		const float** hs = (const float**)W.pinned;
+		const void** hs = (const void**)W.pinned;
 		size_t so = 0;
 		for (int i = 0; i < n; ++i) {
 			if (imgs[i]->on_device) hs[i] = imgs[i]->data;
 			else {
-				float* d = (float*)((char*)W.staging.p + so);
-				HIPCHK(hipMemcpyAsync(d, imgs[i]->data, sizeof(float) * (size_t)sh * sw * 3, hipMemcpyHostToDevice, st));
-				hs[i] = d; so += sizeof(float) * (size_t)sh * sw * 3;
+				void* d = (char*)W.staging.p + so;
+				HIPCHK(hipMemcpyAsync(d, imgs[i]->data, img_bytes, hipMemcpyHostToDevice, st));
+				hs[i] = d; so += img_stride;
 			}
 		}
-		HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(float*) * n, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
 	}
-	plan.srcs = (const float* const*)W.srcs.p;
+	plan.srcs = (const void* const*)W.srcs.p;
 
 	int* d_raw_count = (int*)W.counts.p;
 	int* d_refined_count = d_raw_count + n;
@@ -274,11 +277,12 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 	if (!ctx || !cfg || !imgs || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_sift_batch: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
 	for (int i = 0; i < n; ++i)
-		if (!imgs[i].data || imgs[i].h < 2 || imgs[i].w < 2) OP_FAIL(OP_ERR_INVALID, "op_sift_batch: bad image " + std::to_string(i));
-	// group by size, keep first-appearance order
+		if (!imgs[i].data || imgs[i].h < 2 || imgs[i].w < 2 || (imgs[i].dtype != OP_F32 && imgs[i].dtype != OP_U8))
+			OP_FAIL(OP_ERR_INVALID, "op_sift_batch: bad image " + std::to_string(i));
+	// group by (size, element type), keep first-appearance order
 	std::vector<std::pair<std::pair<int, int>, std::vector<int>>> groups;
 	for (int i = 0; i < n; ++i) {
-		std::pair<int, int> key(imgs[i].h, imgs[i].w);
+		std::pair<int, int> key(imgs[i].h * 2 + imgs[i].dtype, imgs[i].w);
 		bool found = false;
 		for (auto& g : groups) if (g.first == key) { g.second.push_back(i); found = true; break; }
 		if (!found) groups.push_back({key, {i}});
@@ -405,7 +409,7 @@ void op_features_free(op_features* f) {
 
 // ---- staged dump ----
 int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_sift_dump** out) {
-	if (!ctx || !cfg || !img || !img->data || !out) OP_FAIL(OP_ERR_INVALID, "op_sift_staged: bad argument");
+	if (!ctx || !cfg || !img || !img->data || !out || (img->dtype != OP_F32 && img->dtype != OP_U8)) OP_FAIL(OP_ERR_INVALID, "op_sift_staged: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
 	op_sift_dump* d = new op_sift_dump;
 	GroupResult res;

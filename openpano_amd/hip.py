@@ -46,7 +46,10 @@ class OpConfig(C.Structure):
 
 
 class OpImage(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int)]
+    _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int), ("dtype", C.c_int)]
+
+
+OP_F32, OP_U8 = 0, 1
 
 
 class OpBlendImage(C.Structure):
@@ -212,19 +215,22 @@ class Context:
 
 
 def _mk_images(images):
-    """images: list of numpy HWC float32 arrays, or (device_ptr, h, w) tuples."""
+    """images: numpy HWC arrays (float32 in [0,1], or uint8 decoder bytes), or device buffers as
+    (device_ptr, h, w) / (device_ptr, h, w, "u8") tuples."""
     arr = (OpImage * len(images))()
     keep = []
     for i, im in enumerate(images):
         if isinstance(im, tuple):
-            ptr, h, w = im
-            arr[i] = OpImage(C.c_void_p(int(ptr)), int(h), int(w), 1)
+            ptr, h, w = im[:3]
+            dt = OP_U8 if len(im) > 3 and im[3] in ("u8", OP_U8, np.uint8) else OP_F32
+            arr[i] = OpImage(C.c_void_p(int(ptr)), int(h), int(w), 1, dt)
         else:
-            a = np.ascontiguousarray(im, np.float32)
+            im = np.asarray(im)
+            a = np.ascontiguousarray(im) if im.dtype == np.uint8 else np.ascontiguousarray(im, np.float32)
             if a.ndim != 3 or a.shape[2] != 3:
-                raise ValueError("image must be H x W x 3 float32")
+                raise ValueError("image must be H x W x 3 (float32 or uint8)")
             keep.append(a)
-            arr[i] = OpImage(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0)
+            arr[i] = OpImage(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0, OP_U8 if a.dtype == np.uint8 else OP_F32)
     return arr, keep
 
 

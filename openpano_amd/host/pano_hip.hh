@@ -138,7 +138,7 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 		std::vector<Descriptor> do_detect_feature(const Mat32f& mat) const PANO_OVERRIDE {
 			op_ctx* ctx = HipContext::get();
 			const op_config cfg = hip_config_snapshot();
-			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0};
+			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0, OP_F32};
 			if (mat.channels() != 3) { fprintf(stderr, "HipSIFTDetector: image must have 3 channels\n"); exit(1); }
 			op_features* f = nullptr;
 			PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, &im, 1, &f));
@@ -164,7 +164,7 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 			op_ctx* ctx = HipContext::get();
 			const op_config cfg = hip_config_snapshot();
 			std::vector<op_image> ims;
-			for (auto* m : imgs) ims.push_back(op_image{m->ptr(), m->rows(), m->cols(), 0});
+			for (auto* m : imgs) ims.push_back(op_image{m->ptr(), m->rows(), m->cols(), 0, OP_F32});
 			HipFeatureSet fs;
 			PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, ims.data(), (int)ims.size(), &fs.handle));
 			fs.feats.resize(imgs.size());
@@ -478,7 +478,7 @@ class HipCylinderWarper {
 			op_ctx* ctx = HipContext::get();
 			const op_config cfg = hip_config_snapshot();
 			Shape2D shape(mat.width(), mat.height());
-			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0};
+			op_image im{mat.ptr(), mat.rows(), mat.cols(), 0, OP_F32};
 			op_canvas* cv = nullptr;
 			PANO_HIP_CHECK(op_cyl_warp(ctx, &cfg, &im, h_factor, &cv));
 			warp(shape, kpts);

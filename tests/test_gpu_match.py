@@ -62,6 +62,12 @@ def test_edge_cases(ctx, oracle, cfg):
         (rng.random((300, 128)) * 40).astype(np.float32),   # 6: un-normalised random vectors
         (a[:200] + rng.normal(0, 3.0, (200, 128)).astype(np.float32)).clip(0).astype(np.float32),  # 7: noisy copy of 4
         np.zeros((5, 128), np.float32),             # 8: all-zero descriptors
+        # 9/10: more than 8 identical descriptors: every ranked candidate falls inside the error
+        # margin, so the rows take the exact full-scan path (forward and reverse)
+        np.concatenate([np.repeat(a[5:6], 12, axis=0), a[:60], np.repeat(a[70:71], 9, axis=0)]),
+        np.concatenate([a[:40], np.repeat(a[5:6], 11, axis=0), a[60:90]]),
+        # 11: a NaN descriptor (zero-weight window) never matches and never wins a ratio test
+        np.concatenate([a[:30], np.full((1, 128), np.nan, np.float32), a[30:50]]),
     ]
     f = hip.Features.from_host(ctx, sets)
     pairs = [(i, j) for i in range(len(sets)) for j in range(len(sets)) if i != j]

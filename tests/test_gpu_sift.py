@@ -153,3 +153,22 @@ def test_errors_are_reported_not_swallowed(ctx, cfg):
     f = hip.sift_batch(ctx, cfg, [np.full((200, 300, 3), 0.5, np.float32)])
     assert f.count(0) == 0 and f.total == 0
     f.free()
+
+
+def test_uint8_ingest_equals_fp32_path(ctx, oracle, cfg):
+    """OP_U8 sources (decoder bytes, host or device) are converted on the device exactly like
+    read_img, (float)byte / 255.0 (lib/imgio.cc:54-56): same features as the fp32 image, bit for bit."""
+    import torch
+    from openpano_amd import hip
+    world = synth.make_world(61, 300, 420, work_scale=1600.0 / (240 + 320), density=900.0)
+    u8 = [(synth.cut_view(world, 20 + 9 * k, 20 + 40 * k, 240, 320, k) * 255 + 0.5).astype(np.uint8) for k in range(3)]
+    f32 = [(v.astype(np.float64) / 255.0).astype(np.float32) for v in u8]
+    dev = torch.from_numpy(u8[2]).cuda(); torch.cuda.synchronize()
+    fa = hip.sift_batch(ctx, cfg, [u8[0], u8[1], (dev.data_ptr(), 240, 320, "u8"), f32[0]])   # mixed element types in one batch
+    for k in range(3):
+        od, oc = oracle.detect_feature(f32[k])
+        d, c = fa.get(k)
+        assert len(d) > 50 and np.array_equal(d, od) and np.array_equal(c, oc), k
+    d3, c3 = fa.get(3); d0, c0 = fa.get(0)
+    assert np.array_equal(d3, d0) and np.array_equal(c3, c0)
+    fa.free()

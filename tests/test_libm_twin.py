@@ -46,4 +46,4 @@ def test_abi_header_symbols_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.op_abi_version.restype = C.c_int
-    assert lib.op_abi_version() >= 1
+    assert lib.op_abi_version() >= 2
