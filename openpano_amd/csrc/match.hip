@@ -163,7 +163,10 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 	for (int r = 0; r < NK; ++r) { ts[r] = -FLT_MAX; ti[r] = -1; }
 	const int ntiles = (ky + 31) / 32;
 
-	auto load_tile = [&](int t, int buf) {
+	// global -> registers and registers -> LDS are split so that the next tile's loads are in flight
+	// while the MFMAs of the current tile run; the LDS store happens after them
+	f32x4 stage[4]; float stage_ny = 0.f;
+	auto fetch_tile = [&](int t) {
 		// 32 rows x 128 floats = 1024 float4, 4 per thread
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
@@ -172,19 +175,28 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 			const int gy = t * 32 + yr;
 			f32x4 v = {0.f, 0.f, 0.f, 0.f};
 			if (gy < ky) v = *(const f32x4*)(Y + (long long)gy * 128 + c4 * 4);
-			*(f32x4*)(&s_y[buf][yr * YP + c4 * 4]) = v;
+			stage[r] = v;
 		}
 		if (tid < 32) {
 			const int gy = t * 32 + tid;
-			s_nyh[buf][tid] = gy < ky ? 0.5f * ny[gy] : FLT_MAX;   // padded columns can never rank
+			stage_ny = gy < ky ? 0.5f * ny[gy] : FLT_MAX;   // padded columns can never rank
 		}
 	};
+	auto commit_tile = [&](int buf) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int e = tid + 256 * r;
+			*(f32x4*)(&s_y[buf][(e >> 5) * YP + (e & 31) * 4]) = stage[r];
+		}
+		if (tid < 32) s_nyh[buf][tid] = stage_ny;
+	};
 
-	load_tile(0, 0);
+	fetch_tile(0);
+	commit_tile(0);
 	__syncthreads();
 	for (int t = 0; t < ntiles; ++t) {
 		const int buf = t & 1;
-		if (t + 1 < ntiles) load_tile(t + 1, buf ^ 1);
+		if (t + 1 < ntiles) fetch_tile(t + 1);
 		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const float* yrow = &s_y[buf][j * YP + 64 * h];
 #pragma unroll
@@ -202,6 +214,7 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 			const float sc = acc[reg] - s_nyh[buf][i];
 			topk_insert(ts, ti, sc, t * 32 + i);
 		}
+		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		__syncthreads();
 	}
 	// merge the two lane halves of each X row; both halves then read the merged top-4
