@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 	__syncthreads();
 	unsigned short* sp = samples + pa.samp_off;
 	int vsel = -1;                                     // lane q < t: q-th index of the sample being drawn, else -1
+	unsigned long long selmask = 0ULL;                 // m <= 64: bit r set = index r already drawn for this sample
 	int K = 0, t = 0, accepted = 0;
 	while (K < iters) {                                // K, t and the sample are wave-uniform
 		// ---- twist (each phase reads only values the previous phases finished) ----
@@ -128,24 +129,54 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 		__syncthreads();
 		// ---- consume the block in order (:70-77).  The automaton is sequential (the stream position
 		// depends on the rejections), so it runs on the scalar unit: 64 draws at a time sit in one
-		// VGPR across the lanes, v_readlane hands them out one by one, and the sample, its fill
-		// level and the counters are wave-uniform (SGPR) values; accepted draws are collected
-		// lane-wise and staged in LDS 64 at a time. ----
-		int cnt = 0, outv = 0;
+		// VGPR across the lanes, the sample state and the counters are wave-uniform (SGPR) values,
+		// accepted draws go to the LDS staging buffer.
+		//   m <= 64: the selected set is a 64-bit mask, membership is a scalar bit test;
+		//   m  > 64: repeats are rare, so whole samples are accepted at once when the pairwise
+		//            equality masks of the batch show no repeat among their ns draws, else the
+		//            draws are stepped one by one against the set held across the lanes. ----
+		int cnt = 0;
 		for (int base = 0; base < 624 && K < iters; base += 64) {
 			const int v = base + lane < 624 ? (int)rd[base + lane] : 0;
 			const int lim = 624 - base < 64 ? 624 - base : 64;
-			for (int i = 0; i < lim && K < iters; ++i) {
-				const int r = __builtin_amdgcn_readlane(v, i);
-				if (__ballot(vsel == r) != 0ULL) continue;           // already selected (:73-75); lane q < t holds sel[q]
-				vsel = lane == t ? r : vsel;
-				if (lane == (cnt & 63)) outv = r;
-				++cnt;
-				if ((cnt & 63) == 0) ob[cnt - 64 + lane] = (unsigned short)outv;
-				if (++t == ns) { t = 0; ++K; vsel = -1; }
+			if (m <= 64) {
+				for (int i = 0; i < lim && K < iters; ++i) {
+					const int r = __builtin_amdgcn_readlane(v, i);
+					if ((selmask >> r) & 1ULL) continue;                 // already selected (:73-75)
+					selmask |= 1ULL << r;
+					if (lane == i) ob[cnt] = (unsigned short)v;
+					++cnt;
+					if (++t == ns) { t = 0; ++K; selmask = 0ULL; }
+				}
+			} else {
+				unsigned long long eq[7];                                // bit l of eq[d-1]: draw l == draw l+d
+#pragma unroll
+				for (int d = 1; d <= 7; ++d) {
+					const int o = __shfl_down(v, d);                     // all lanes active: a pull from a masked-off lane reads 0
+					eq[d - 1] = __ballot(lane + d < lim && v == o);
+				}
+				int i = 0;
+				while (i < lim && K < iters) {
+					if (t == 0 && i + ns <= lim) {
+						unsigned long long bad = 0ULL;
+#pragma unroll
+						for (int d = 1; d <= 7; ++d) if (d < ns) bad |= (eq[d - 1] >> i) & ((1ULL << (ns - d)) - 1ULL);
+						if (bad == 0ULL) {                               // ns distinct draws: one whole sample
+							if (lane >= i && lane < i + ns) ob[cnt + lane - i] = (unsigned short)v;
+							cnt += ns; ++K; i += ns;
+							continue;
+						}
+					}
+					const int r = __builtin_amdgcn_readlane(v, i);
+					++i;
+					if (__ballot(vsel == r) != 0ULL) continue;           // already selected; lane q < t holds sel[q]
+					vsel = lane == t ? r : vsel;
+					if (lane == i - 1) ob[cnt] = (unsigned short)v;
+					++cnt;
+					if (++t == ns) { t = 0; ++K; vsel = -1; }
+				}
 			}
 		}
-		if (lane < (cnt & 63)) ob[(cnt & ~63) + lane] = (unsigned short)outv;
 		__syncthreads();
 		for (int i = lane; i < cnt; i += 64) {           // accepted draw number -> (hypothesis, slot)
 			const int a = accepted + i;
