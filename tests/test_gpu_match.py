@@ -99,3 +99,29 @@ def test_full_size_properties(ctx, oracle, cfg):
         want = oracle.match_exact(f.get(i)[0], f.get(j)[0])
         assert np.array_equal(got[(i, j)], want)
     f.free()
+
+
+def test_config5_sized_sets(ctx, oracle, cfg):
+    """BASELINE config 5 scale for the matcher: K ~ 4000 descriptors per image (the MFMA
+    match-matrix stress).  Properties over all pairs of 6 sets + exact oracle check of two pairs."""
+    from openpano_amd import hip
+    rng = np.random.default_rng(5)
+    a = np.load(os.path.join(HERE, "golden", "sift_d_500x700.npz"))["desc"]
+    base = np.concatenate([a] * (4000 // len(a) + 1))[:4000]
+    sets = []
+    for k in range(6):
+        # RootSIFT-like rows: a noisy, shuffled copy of a common base so that true matches exist
+        x = np.abs(base + rng.normal(0, 6.0 + 2 * k, base.shape)).astype(np.float32)
+        x = (np.sqrt(x / x.sum(axis=1, keepdims=True)) * 512).astype(np.float32)
+        sets.append(x[rng.permutation(len(x))[: 3600 + 80 * k]])
+    f = hip.Features.from_host(ctx, sets)
+    pairs = [(i, j) for i in range(6) for j in range(6) if i != j]
+    got = dict(zip(pairs, hip.match_pairs(ctx, cfg, f, pairs)))
+    for i in range(6):
+        for j in range(i + 1, 6):
+            assert sorted(map(tuple, got[(i, j)])) == sorted(map(tuple, got[(j, i)][:, ::-1]))
+            if len(got[(i, j)]):
+                assert len(set(got[(i, j)][:, 0])) == len(got[(i, j)]) == len(set(got[(i, j)][:, 1]))
+    for (i, j) in [(0, 1), (5, 2)]:
+        assert np.array_equal(got[(i, j)], oracle.match_exact(sets[i], sets[j]))
+    f.free()

@@ -172,3 +172,27 @@ def test_uint8_ingest_equals_fp32_path(ctx, oracle, cfg):
     d3, c3 = fa.get(3); d0, c0 = fa.get(0)
     assert np.array_equal(d3, d0) and np.array_equal(c3, c0)
     fa.free()
+
+
+def test_config5_sized_image(ctx, oracle, cfg):
+    """BASELINE config 5 input size: a 4000x3000 decoder-byte image (36 MB as uint8, 144 MB as
+    fp32) is down-scaled to the 914x685 working image on the device; features equal the oracle's on
+    the fp32 image bit for bit, through both element types."""
+    import torch
+    from openpano_amd import hip
+    rng = np.random.default_rng(50000)
+    # cheap large texture: a small seeded world up-sampled by pixel replication + per-pixel noise
+    base = synth.make_world(505, 375, 500, work_scale=1.0, density=60.0)
+    big = np.repeat(np.repeat(base, 8, axis=0), 8, axis=1)
+    big = np.clip(big + rng.normal(0, 0.02, big.shape).astype(np.float32), 0, 1)
+    u8 = (big * 255 + 0.5).astype(np.uint8)
+    assert u8.shape == (3000, 4000, 3)
+    f32 = (u8.astype(np.float64) / 255.0).astype(np.float32)
+    od, oc = oracle.detect_feature(f32)
+    assert len(od) > 300
+    t = torch.from_numpy(u8).cuda(); torch.cuda.synchronize()
+    f = hip.sift_batch(ctx, cfg, [(t.data_ptr(), 3000, 4000, "u8"), f32])
+    for k in range(2):
+        d, c = f.get(k)
+        assert np.array_equal(d, od) and np.array_equal(c, oc), k
+    f.free()
