@@ -73,6 +73,33 @@ def cpu_baseline(cfg, views, log):
     }
 
 
+def match_cpu_baseline(cfg, feats, log):
+    """The reference's match loop on this box's host cores, bounded sample: the first 128 pairs of
+    the workload's pair list with (a) PairWiseMatcher as shipped (FLANN kd-forest, incl. build) and
+    (b) the exact FeatureMatcher (the parity oracle), OpenMP over pairs like stitcher.cc:106-109."""
+    from checkers import Oracle, Ref, ref_available
+    cores = os.cpu_count() or 1
+    n = feats.num_images
+    descs = [feats.get(i)[0] for i in range(n)]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)][:128]
+    out = {"cores": cores, "sample": f"first {len(pairs)} of the {n * (n - 1) // 2} pairs, OpenMP over pairs with {cores} threads"}
+    eng = None
+    try:
+        if ref_available():
+            eng = Ref(cfg); out["kind"] = "reference"
+    except OSError as e:
+        log(f"oracle/_ref unusable ({e})")
+    if eng is None:
+        eng = Oracle(cfg); out["kind"] = "port"
+    eng.match_pairs_batch(descs, pairs[:8], cores)                  # warm
+    t0 = time.perf_counter(); m = eng.match_pairs_batch(descs, pairs, cores); t = time.perf_counter() - t0
+    out["exact_image_pairs_per_s"] = len(pairs) / t; out["exact_matches"] = int(m)
+    if out["kind"] == "reference":
+        t0 = time.perf_counter(); m2 = eng.match_pairs_batch(descs, pairs, cores, flann=True); t2 = time.perf_counter() - t0
+        out["flann_image_pairs_per_s"] = len(pairs) / t2; out["flann_matches"] = int(m2)
+    return out
+
+
 def run_ingest(hip, ctx, cfg, views, k_rank, args):
     """SIFT over HOST-resident images (the reference hands over Mat32f in host RAM, stitcherbase.cc:16):
     every call pays the H2D copies.  fp32 Mat32f (12 B/px) vs decoder bytes (3 B/px, converted on the
@@ -293,6 +320,8 @@ def main():
         t0 = time.perf_counter()
         out["cpu_baseline"] = cpu_baseline(cfg, views, log)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if out.get("match"):
+            out["match"]["cpu_baseline"] = match_cpu_baseline(cfg, feats, log)
         log(f"cpu baseline took {time.perf_counter() - t0:.1f} s")
     elif rank == 0:
         out["cpu_baseline"] = None

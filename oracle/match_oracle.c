@@ -7,6 +7,7 @@
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 #include "oracle.h"
 
 /* feature/dist.cc:22-57: four stride-4 partial sums (one per SSE lane), horizontal add
@@ -66,4 +67,24 @@ int orc_match_exact(const orc_sift_cfg* cfg, const float* d1, int n1, const floa
 	}
 	qsort(out, cnt, 2 * sizeof(int), pair_cmp);
 	return cnt;
+}
+
+/* the match loop of Stitcher::pairwise_match (stitch/stitcher.cc:96-113) with the exact matcher,
+ * omp-parallel over the pair list; returns the total number of matches */
+long orc_match_pairs_batch(const orc_sift_cfg* cfg, const float* desc, const int* counts, int n, const int* pairs, int npairs, int nthreads) {
+	long* offs = (long*)malloc(sizeof(long) * (n + 1));
+	offs[0] = 0;
+	for (int i = 0; i < n; ++i) offs[i + 1] = offs[i] + counts[i];
+	long total = 0;
+	omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic) reduction(+:total)
+	for (int p = 0; p < npairs; ++p) {
+		const int i = pairs[2 * p], j = pairs[2 * p + 1];
+		const int mn = counts[i] < counts[j] ? counts[i] : counts[j];
+		int* out = (int*)malloc(sizeof(int) * 2 * (mn > 0 ? mn : 1));
+		total += orc_match_exact(cfg, desc + offs[i] * 128, counts[i], desc + offs[j] * 128, counts[j], out);
+		free(out);
+	}
+	free(offs);
+	return total;
 }

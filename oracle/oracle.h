@@ -77,6 +77,8 @@ void orc_libm_batch(int which, const float* x, const float* y, long n, float* ou
 float orc_euclidean_sqr(const float* x, const float* y, int n, float now_thres);	/* feature/dist.cc:22-57 */
 int orc_match_exact(const orc_sift_cfg* cfg, const float* d1, int n1, const float* d2, int n2, int* out_pairs);
 
+long orc_match_pairs_batch(const orc_sift_cfg* cfg, const float* desc, const int* counts, int n, const int* pairs, int npairs, int nthreads);
+
 /* ---- RANSAC: TransformEstimation::get_transform (stitch/transform_estimate.cc:26-218), seed injected ---- */
 int orc_ransac(const int* match, int m, const double* kp1, int nk1, const double* kp2, int nk2,
 		int w1, int h1, int w2, int h2, int affine, int iterations, double ransac_inlier_thres_cfg,

@@ -238,6 +238,29 @@ int ref_match_flann(const float* d1, int n1, const float* d2, int n2, int* out) 
 	return md.size();
 }
 
+// The match loop of Stitcher::pairwise_match (stitch/stitcher.cc:96-113) on the host cores:
+// omp-parallel over the pair list with (use_flann=1) the shipped PairWiseMatcher incl. its
+// kd-forest build, or (0) the exact FeatureMatcher.  Returns the total number of matches.
+long ref_match_pairs_batch(const float* desc, const int* counts, int n, const int* pairs, int npairs, int nthreads, int use_flann) {
+	std::vector<std::vector<Descriptor>> feats(n);
+	size_t off = 0;
+	for (int i = 0; i < n; ++i) { feats[i] = wrap_desc(desc + off * 128, counts[i]); off += counts[i]; }
+	omp_set_num_threads(nthreads);
+	long total = 0;
+	if (use_flann) {
+		PairWiseMatcher pw(feats);
+#pragma omp parallel for schedule(dynamic) reduction(+:total)
+		for (int p = 0; p < npairs; ++p) total += pw.match(pairs[2 * p], pairs[2 * p + 1]).size();
+	} else {
+#pragma omp parallel for schedule(dynamic) reduction(+:total)
+		for (int p = 0; p < npairs; ++p) {
+			FeatureMatcher m(feats[pairs[2 * p]], feats[pairs[2 * p + 1]]);
+			total += m.match().size();
+		}
+	}
+	return total;
+}
+
 // TransformEstimation(...).get_transform(&info) (stitch/transform_estimate.cc:26-87) with an injected
 // seed. inlier_pts receives info.match as (to.x, to.y, from.x, from.y) rows. Returns the bool.
 int ref_ransac(const int* match, int m, const double* kp1, int nk1, const double* kp2, int nk2,

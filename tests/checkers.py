@@ -161,6 +161,8 @@ class Oracle(_StagedBase):
                                    C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_uint,
                                    C.POINTER(C.c_float), _f64p, _i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
+        lib.orc_match_pairs_batch.restype = C.c_long
+        lib.orc_match_pairs_batch.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int]
         lib.orc_blend_prepare.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_void_p, _f64p, _f64p]
         lib.orc_blend_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.orc_blend_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]
@@ -271,6 +273,13 @@ class Oracle(_StagedBase):
         n = self.lib.orc_match_exact(self._cp(), d1.reshape(-1), len(d1), d2.reshape(-1), len(d2), out.reshape(-1))
         return out[:n].copy()
 
+    def match_pairs_batch(self, descs, pairs, nthreads, flann=False):
+        """match loop of Stitcher::pairwise_match over a pair list on `nthreads` host cores -> #matches"""
+        flat = np.ascontiguousarray(np.concatenate(descs), np.float32)
+        counts = np.array([len(d) for d in descs], np.int32)
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        return self.lib.orc_match_pairs_batch(self._cp(), flat.reshape(-1), counts, len(descs), pr.reshape(-1), len(pr), nthreads)
+
     def euclidean_sqr(self, x, y, thres=np.float32(3.4e38)):
         return self.lib.orc_euclidean_sqr(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), len(x), thres)
 
@@ -304,6 +313,8 @@ class Ref(_StagedBase):
         lib.ref_euclidean_sqr.restype = C.c_float
         lib.ref_euclidean_sqr.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
         lib.ref_gauss_kernel.argtypes = [C.c_float, _f32p]
+        lib.ref_match_pairs_batch.restype = C.c_long
+        lib.ref_match_pairs_batch.argtypes = [_f32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int]
         lib.ref_ransac.argtypes = [_i32p, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint,
                                    C.POINTER(C.c_float), _f64p, _f64p, C.POINTER(C.c_int)]
 
@@ -399,6 +410,12 @@ class Ref(_StagedBase):
         out = np.empty((max(1, min(len(d1), len(d2))), 2), np.int32)
         n = self.lib.ref_match_exact(d1.reshape(-1), len(d1), d2.reshape(-1), len(d2), out.reshape(-1))
         return out[:n].copy()
+
+    def match_pairs_batch(self, descs, pairs, nthreads, flann=False):
+        flat = np.ascontiguousarray(np.concatenate(descs), np.float32)
+        counts = np.array([len(d) for d in descs], np.int32)
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        return self.lib.ref_match_pairs_batch(flat.reshape(-1), counts, len(descs), pr.reshape(-1), len(pr), nthreads, int(flann))
 
     def match_flann(self, d1, d2):
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
