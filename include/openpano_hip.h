@@ -237,6 +237,13 @@ int op_canvas_dims(const op_canvas* c, int* h, int* w);
 const float* op_canvas_device(const op_canvas* c);
 int op_canvas_copy(op_ctx* ctx, const op_canvas* c, float* host);
 void op_canvas_free(op_canvas* c);
+/* crop(mat) (lib/imgproc.cc:200-235, called by main.cc:226-229 under config CROP): the largest
+ * rectangle of valid pixels, first maximum in (line, column) scan order like the reference.
+ * x0 / y0 (optional) receive the rectangle's origin in c.  The result may be empty (h = 0). */
+int op_canvas_crop(op_ctx* ctx, const op_canvas* c, op_canvas** out, int* x0, int* y0);
+/* write_rgb / write_png quantisation (lib/imgio.cc:25-40,98-113): Color::NO -> white, v * 255
+ * truncated to a byte; D2H of H x W x 3 bytes instead of the fp32 canvas */
+int op_canvas_copy_u8(op_ctx* ctx, const op_canvas* c, unsigned char* host);
 
 /* CYLINDER mode pre-warp -- replaces CylinderWarper::warp (stitch/warp.hh:47-55, warp.cc:13-75).
  * op_cyl_warp_shape is the host part (projector, output shape, offset and the keypoints, which

@@ -262,6 +262,116 @@ __global__ void __launch_bounds__(256) k_cyl_project(CylParams P, const float* _
 	p[0] = c[0]; p[1] = c[1]; p[2] = c[2];
 }
 
+// ---- crop (lib/imgproc.cc:200-235): the largest rectangle of valid pixels ----
+// Stage 1: column histograms.  height[line][k] = number of consecutive valid pixels ending at
+// (line, k); thread per column walks the lines (coalesced across k).
+__global__ void __launch_bounds__(256) k_crop_heights(const float* __restrict__ mat, int h, int w, int* __restrict__ height) {
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= w) return;
+	int run = 0;
+	for (int line = 0; line < h; ++line) {
+		const float* p = mat + ((long long)line * w + k) * 3;
+		const float m = fmaxf(fmaxf(p[0], p[1]), p[2]);
+		run = m < 0 ? 0 : run + 1;                        // find Color::NO (:209)
+		height[(long long)line * w + k] = run;
+	}
+}
+// Stage 2: per line, the largest rectangle under the histogram.  left/right of the reference's
+// pointer-jumping loops (:212-221) are the extents over which height >= height[k]; each thread
+// finds them with a two-level search (own 64-chunk, chunk minima, target chunk).  The block's
+// best (area, k) keeps the reference's first-maximum rule (:222-224: strict update in k order).
+constexpr int CROP_CHUNK = 64;
+__global__ void __launch_bounds__(256) k_crop_lines(const int* __restrict__ height, int h, int w, int4* __restrict__ line_best) {
+	extern __shared__ int s_crop[];
+	int* hs = s_crop;                    // w heights of this line
+	int* cmin = hs + w;                  // minima of 64-chunks
+	__shared__ int s_area[256], s_k[256], s_l[256], s_r[256];
+	const int line = blockIdx.x, tid = threadIdx.x;
+	const int nchunk = (w + CROP_CHUNK - 1) / CROP_CHUNK;
+	for (int k = tid; k < w; k += 256) hs[k] = height[(long long)line * w + k];
+	__syncthreads();
+	for (int c = tid; c < nchunk; c += 256) {
+		int m = 0x7fffffff;
+		for (int k = c * CROP_CHUNK; k < w && k < (c + 1) * CROP_CHUNK; ++k) m = hs[k] < m ? hs[k] : m;
+		cmin[c] = m;
+	}
+	__syncthreads();
+	int barea = 0, bk = 0x7fffffff, bl = 0, br = 0;
+	for (int k = tid; k < w; k += 256) {
+		const int hk = hs[k];
+		if (hk == 0) continue;                           // area 0 never beats maxarea (strict >, initial 0)
+		// left: first j < k with hs[j] < hk, +1
+		int j = k - 1;
+		const int c0 = k / CROP_CHUNK;
+		while (j >= c0 * CROP_CHUNK && hs[j] >= hk) --j;
+		if (j < c0 * CROP_CHUNK && j >= 0) {
+			int c = c0 - 1;
+			while (c >= 0 && cmin[c] >= hk) --c;
+			if (c < 0) j = -1;
+			else { j = (c + 1) * CROP_CHUNK - 1; while (hs[j] >= hk) --j; }
+		}
+		const int left = j + 1;
+		// right: first j > k with hs[j] < hk, -1
+		j = k + 1;
+		const int cend = (c0 + 1) * CROP_CHUNK < w ? (c0 + 1) * CROP_CHUNK : w;
+		while (j < cend && hs[j] >= hk) ++j;
+		if (j >= cend && j < w) {
+			int c = c0 + 1;
+			while (c < nchunk && cmin[c] >= hk) ++c;
+			if (c >= nchunk) j = w;
+			else { j = c * CROP_CHUNK; while (hs[j] >= hk) ++j; }
+		}
+		const int right = j - 1;
+		const int area = (right - left + 1) * hk;
+		if (area > barea) { barea = area; bk = k; bl = left; br = right; }   // ascending k per thread: first max
+	}
+	s_area[tid] = barea; s_k[tid] = bk; s_l[tid] = bl; s_r[tid] = br;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (tid < st) {
+			const int oa = s_area[tid + st], ok = s_k[tid + st];
+			if (oa > s_area[tid] || (oa == s_area[tid] && ok < s_k[tid])) { s_area[tid] = oa; s_k[tid] = ok; s_l[tid] = s_l[tid + st]; s_r[tid] = s_r[tid + st]; }
+		}
+		__syncthreads();
+	}
+	if (tid == 0) line_best[line] = make_int4(s_area[0], s_l[0], s_r[0], s_area[0] > 0 ? hs[s_k[0]] : 0);
+}
+// Stage 3: first line with the maximal area (update_max is strict, lines ascend)
+__global__ void __launch_bounds__(256) k_crop_pick(const int4* __restrict__ line_best, int h, int* __restrict__ rect /* x0,y0,w,h */) {
+	__shared__ int s_area[256], s_line[256];
+	int ba = 0, bl = 0x7fffffff;
+	for (int l = threadIdx.x; l < h; l += 256) { const int a = line_best[l].x; if (a > ba) { ba = a; bl = l; } }
+	s_area[threadIdx.x] = ba; s_line[threadIdx.x] = bl;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (threadIdx.x < st) {
+			const int oa = s_area[threadIdx.x + st], ol = s_line[threadIdx.x + st];
+			if (oa > s_area[threadIdx.x] || (oa == s_area[threadIdx.x] && ol < s_line[threadIdx.x])) { s_area[threadIdx.x] = oa; s_line[threadIdx.x] = ol; }
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		if (s_area[0] <= 0) { rect[0] = 0; rect[1] = 1; rect[2] = 1; rect[3] = 0; }     // ll = rr = hh = nl = 0 (:205)
+		else {
+			const int4 b = line_best[s_line[0]];
+			rect[0] = b.y; rect[1] = s_line[0] - b.w + 1; rect[2] = b.z - b.y + 1; rect[3] = b.w;
+		}
+	}
+}
+__global__ void __launch_bounds__(256) k_crop_copy(const float* __restrict__ src, int sw, int x0, int y0, float* __restrict__ dst, int dh, int dw) {
+	const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (e >= (long long)dh * dw * 3) return;
+	const int row = (int)(e / (dw * 3)), c = (int)(e % (dw * 3));
+	dst[e] = src[((long long)(row + y0) * sw + x0) * 3 + c];
+}
+// write_rgb / write_png quantisation (lib/imgio.cc:25-40,98-113): Color::NO -> white, float * 255 truncated
+__global__ void __launch_bounds__(256) k_to_u8(const float* __restrict__ src, long long n, unsigned char* __restrict__ dst) {
+	const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (e >= n) return;
+	const float v = src[e];
+	dst[e] = (unsigned char)((v < 0 ? 1.f : v) * 255.f);
+}
+
 // ------------------------------- host geometry (fp64, host libm) -------------------------------
 // Eigen::FullPivLU 3x3 inverse used by Homography::inverse (stitch/homography.cc:25-39)
 bool inverse3_host(const double a[9], double inv[9]) {
@@ -527,6 +637,62 @@ void op_canvas_free(op_canvas* c) {
 	hipSetDevice(c->device);
 	pool_free(c->data);
 	delete c;
+}
+
+int op_canvas_crop(op_ctx* ctx, const op_canvas* c, op_canvas** out, int* x0, int* y0) {
+	if (!ctx || !c || !out) OP_FAIL(OP_ERR_INVALID, "op_canvas_crop: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const int h = c->h, w = c->w;
+	if ((size_t)(w + (w + CROP_CHUNK - 1) / CROP_CHUNK) * sizeof(int) > 150 * 1024) OP_FAIL(OP_ERR_UNSUPPORTED, "op_canvas_crop: canvas wider than 38000 px");
+	Freer fr;
+	int* d_height = nullptr; int4* d_best = nullptr; int* d_rect = nullptr;
+	HIPCHK(pool_alloc((void**)&d_height, sizeof(int) * (size_t)h * w)); fr.v.push_back(d_height);
+	HIPCHK(pool_alloc((void**)&d_best, sizeof(int4) * h)); fr.v.push_back(d_best);
+	HIPCHK(pool_alloc((void**)&d_rect, sizeof(int) * 4)); fr.v.push_back(d_rect);
+	static bool attr_set = false;
+	if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_crop_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr_set = true; }
+	int rect[4];
+	{ ProfScope ps(ctx, "crop");
+	  hipLaunchKernelGGL(k_crop_heights, dim3((w + 255) / 256), dim3(256), 0, st, c->data, h, w, d_height);
+	  HIPCHK(hipGetLastError());
+	  const size_t lds = sizeof(int) * (size_t)(w + (w + CROP_CHUNK - 1) / CROP_CHUNK);
+	  hipLaunchKernelGGL(k_crop_lines, dim3(h), dim3(256), lds, st, d_height, h, w, d_best);
+	  HIPCHK(hipGetLastError());
+	  hipLaunchKernelGGL(k_crop_pick, dim3(1), dim3(256), 0, st, d_best, h, d_rect);
+	  HIPCHK(hipGetLastError()); }
+	HIPCHK(hipMemcpyAsync(rect, d_rect, sizeof(rect), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	op_canvas* cv = new op_canvas;
+	cv->h = rect[3]; cv->w = rect[2]; cv->device = ctx->device;
+	const size_t n = (size_t)cv->h * cv->w * 3;
+	if (pool_alloc((void**)&cv->data, sizeof(float) * (n ? n : 1)) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_canvas_crop: allocation failed"); }
+	if (n) {
+		hipLaunchKernelGGL(k_crop_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->data, w, rect[0], rect[1], cv->data, cv->h, cv->w);
+		hipError_t e = hipGetLastError();
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e != hipSuccess) { pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_canvas_crop: ") + hipGetErrorString(e)); }
+	}
+	resolve_profile(ctx);
+	if (x0) *x0 = rect[0];
+	if (y0) *y0 = rect[1];
+	*out = cv;
+	return OP_OK;
+}
+
+int op_canvas_copy_u8(op_ctx* ctx, const op_canvas* c, unsigned char* host) {
+	if (!ctx || !c || !host) OP_FAIL(OP_ERR_INVALID, "op_canvas_copy_u8: bad argument");
+	HIPCHK(hipSetDevice(ctx->device));
+	const long long n = (long long)c->h * c->w * 3;
+	if (n == 0) return OP_OK;
+	Freer fr;
+	unsigned char* d = nullptr;
+	HIPCHK(pool_alloc((void**)&d, (size_t)n)); fr.v.push_back(d);
+	hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c->data, n, d);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(host, d, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return OP_OK;
 }
 
 int op_cyl_warp_shape(const op_config* cfg, int w, int h, double h_factor, double* pts, int npts,

@@ -164,6 +164,8 @@ def lib():
     L.op_canvas_device.argtypes = [C.c_void_p]
     L.op_canvas_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_canvas_free.argtypes = [C.c_void_p]
+    L.op_canvas_crop.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_canvas_copy_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_cyl_warp_shape.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
     L.op_cyl_warp.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_double, C.POINTER(C.c_void_p)]
@@ -523,6 +525,18 @@ class Canvas:
     def numpy(self):
         out = np.empty((self.h, self.w, 3), np.float32)
         check(lib().op_canvas_copy(self.ctx.handle, self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def crop(self):
+        """crop() of the reference (lib/imgproc.cc:200-235) -> (Canvas, (x0, y0))"""
+        h = C.c_void_p(); x0, y0 = C.c_int(), C.c_int()
+        check(lib().op_canvas_crop(self.ctx.handle, self.handle, C.byref(h), C.byref(x0), C.byref(y0)))
+        return Canvas(self.ctx, h), (x0.value, y0.value)
+
+    def numpy_u8(self):
+        """write_rgb quantisation on the device, bytes over PCIe"""
+        out = np.empty((self.h, self.w, 3), np.uint8)
+        check(lib().op_canvas_copy_u8(self.ctx.handle, self.handle, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def free(self):

@@ -426,8 +426,10 @@ inline op_blend_geom hip_blend_prepare(const Bundle& b, std::vector<double>& hin
 // own homo_inv / range / proj_range (already filled by calc_inverse_homo / update_proj_range)
 // and the resolution of get_final_resolution(); the blender is chosen like the reference does
 // (config::MULTIBAND > 0 ? MultiBandBlender : LinearBlender).
+// crop = true additionally applies crop() (lib/imgproc.cc:200-235; main.cc:226-229 under config
+// CROP) on the device, so only the cropped pixels cross PCIe.
 template <typename Bundle>
-inline Mat32f hip_blend(const Bundle& b) {
+inline Mat32f hip_blend(const Bundle& b, bool crop = false) {
 	op_ctx* ctx = HipContext::get();
 	const op_config cfg = hip_config_snapshot();
 	const int n = (int)b.component.size();
@@ -447,6 +449,12 @@ inline Mat32f hip_blend(const Bundle& b) {
 	}
 	op_canvas* cv = nullptr;
 	PANO_HIP_CHECK(op_blend(ctx, &cfg, &g, ims.data(), n, &cv));
+	if (crop) {
+		op_canvas* cc = nullptr;
+		PANO_HIP_CHECK(op_canvas_crop(ctx, cv, &cc, nullptr, nullptr));
+		op_canvas_free(cv);
+		cv = cc;
+	}
 	int h, w;
 	PANO_HIP_CHECK(op_canvas_dims(cv, &h, &w));
 	Mat32f out(h, w, 3);

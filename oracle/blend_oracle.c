@@ -465,3 +465,38 @@ int orc_cyl_project(const float* img, int h, int w, double h_factor, float focal
 	}
 	return 0;
 }
+
+/* ---- crop (lib/imgproc.cc:200-235): largest all-valid rectangle, first maximum in (line, k) order ---- */
+int orc_crop_rect(const float* mat, int h, int w, int* x0, int* y0, int* cw, int* ch) {
+	int* height = (int*)calloc(w, sizeof(int));
+	int* left = (int*)malloc(sizeof(int) * w);
+	int* right = (int*)malloc(sizeof(int) * w);
+	int maxarea = 0, ll = 0, rr = 0, hh = 0, nl = 0;
+	for (int line = 0; line < h; ++line) {
+		for (int k = 0; k < w; ++k) {
+			const float* p = mat + ((size_t)line * w + k) * 3;
+			float m = p[0] > p[1] ? p[0] : p[1]; m = m > p[2] ? m : p[2];	/* max(max(p0,p1),p2) */
+			height[k] = m < 0 ? 0 : height[k] + 1;
+		}
+		for (int k = 0; k < w; ++k) {
+			left[k] = k;
+			while (left[k] > 0 && height[k] <= height[left[k] - 1]) left[k] = left[left[k] - 1];
+		}
+		for (int k = w - 1; k >= 0; --k) {
+			right[k] = k;
+			while (right[k] < w - 1 && height[k] <= height[right[k] + 1]) right[k] = right[right[k] + 1];
+		}
+		for (int k = 0; k < w; ++k) {
+			const int area = (right[k] - left[k] + 1) * height[k];
+			if (maxarea < area) { maxarea = area; ll = left[k]; rr = right[k]; hh = height[k]; nl = line; }
+		}
+	}
+	*x0 = ll; *y0 = nl - hh + 1; *cw = rr - ll + 1; *ch = hh;
+	free(height); free(left); free(right);
+	return maxarea;
+}
+
+/* write_rgb / write_png quantisation (lib/imgio.cc:25-40,98-113): Color::NO -> white, float * 255 truncated */
+void orc_to_u8(const float* mat, long n, unsigned char* out) {
+	for (long i = 0; i < n; ++i) out[i] = (unsigned char)((mat[i] < 0 ? 1 : mat[i]) * 255);
+}

@@ -110,6 +110,11 @@ int orc_cyl_shape(int w, int h, double h_factor, float focal_length, double* pts
 		int* new_w, int* new_h, double* offset);
 int orc_cyl_project(const float* img, int h, int w, double h_factor, float focal_length, float* out);
 
+/* crop (lib/imgproc.cc:200-235): rectangle of the result inside mat; returns its area (0: nothing valid) */
+int orc_crop_rect(const float* mat, int h, int w, int* x0, int* y0, int* cw, int* ch);
+/* write_rgb quantisation (lib/imgio.cc:98-113) */
+void orc_to_u8(const float* mat, long n, unsigned char* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,4 +364,11 @@ void ref_cyl_warp_get(void* hd, float* out, double* pts) {
 }
 void ref_cyl_warp_free(void* hd) { delete (CylRun*)hd; }
 
+// crop(mat) (lib/imgproc.cc:200-235): returns the cropped dims; out (if non-null) receives the pixels
+void ref_crop(const float* rgb, int h, int w, int* ch, int* cw, float* out) {
+	Mat32f r = crop(wrap_rgb(rgb, h, w));
+	*ch = r.height(); *cw = r.width();
+	if (out) memcpy(out, r.ptr(), sizeof(float) * (size_t)r.height() * r.width() * 3);
+}
+
 }	// extern "C"

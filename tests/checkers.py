@@ -204,6 +204,21 @@ class Oracle(_StagedBase):
                                    geom.resolution[0], geom.resolution[1]]), ranges=ranges, homo_inv=hinv)
         return out, meta
 
+    def crop(self, mat):
+        """crop(mat) (lib/imgproc.cc:200-235) -> cropped array (view semantics: a copy)"""
+        mat = np.ascontiguousarray(mat, np.float32)
+        self.lib.orc_crop_rect.argtypes = [_f32p, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+        x0, y0, cw, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.orc_crop_rect(mat.reshape(-1), mat.shape[0], mat.shape[1], C.byref(x0), C.byref(y0), C.byref(cw), C.byref(ch))
+        return mat[y0.value: y0.value + ch.value, x0.value: x0.value + cw.value].copy(), (x0.value, y0.value)
+
+    def to_u8(self, mat):
+        mat = np.ascontiguousarray(mat, np.float32)
+        out = np.empty(mat.shape, np.uint8)
+        self.lib.orc_to_u8.argtypes = [_f32p, C.c_long, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+        self.lib.orc_to_u8(mat.reshape(-1), mat.size, out.reshape(-1))
+        return out
+
     def cyl_warp(self, img, h_factor, pts, cfg=None):
         """CylinderWarper(h_factor).warp(mat, kpts) -> (warped (H', W', 3), pts')"""
         cfg = cfg or self.cfg
@@ -352,6 +367,15 @@ class Ref(_StagedBase):
         self.lib.ref_blend_meta(hd, geom, ranges.reshape(-1), hinv.reshape(-1))
         self.lib.ref_blend_free(hd)
         return out, dict(geom=geom, ranges=ranges, homo_inv=hinv)
+
+    def crop(self, mat):
+        mat = np.ascontiguousarray(mat, np.float32)
+        self.lib.ref_crop.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+        ch, cw = C.c_int(), C.c_int()
+        self.lib.ref_crop(mat.reshape(-1), mat.shape[0], mat.shape[1], C.byref(ch), C.byref(cw), None)
+        out = np.empty((ch.value, cw.value, 3), np.float32)
+        self.lib.ref_crop(mat.reshape(-1), mat.shape[0], mat.shape[1], C.byref(ch), C.byref(cw), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def cyl_warp(self, img, h_factor, pts):
         self._bind_blend()

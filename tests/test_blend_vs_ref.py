@@ -73,3 +73,31 @@ def test_cyl_warp_oracle_equals_reference(ref, oracle, cfg, h, w, hf):
     assert np.array_equal(wp, gp)
     assert np.array_equal(want, got)
     assert (want < 0).any() and (want >= 0).mean() > 0.5
+
+
+def _holey_canvas(seed, h, w):
+    """a blend-like canvas: valid interior with Color::NO borders, notches and holes"""
+    rng = np.random.default_rng(seed)
+    m = rng.random((h, w, 3), dtype=np.float32)
+    m[: rng.integers(2, 9)] = -1; m[-rng.integers(1, 7):] = -1
+    m[:, : rng.integers(1, 12)] = -1; m[:, -rng.integers(3, 15):] = -1
+    for _ in range(6):
+        y, x = rng.integers(0, h), rng.integers(0, w)
+        m[y: y + rng.integers(1, 10), x: x + rng.integers(1, 14)] = -1
+    return m
+
+
+@pytest.mark.parametrize("seed,h,w", [(1, 60, 90), (2, 75, 41), (3, 33, 200), (4, 5, 7)])
+def test_crop_oracle_equals_reference(ref, oracle, seed, h, w):
+    m = _holey_canvas(seed, h, w)
+    want = ref.crop(m)
+    got, _ = oracle.crop(m)
+    assert want.shape == got.shape and np.array_equal(want, got)
+    assert want.size > 0 or h < 10
+
+
+def test_crop_all_invalid_and_all_valid(ref, oracle):
+    full = np.random.default_rng(0).random((20, 30, 3), dtype=np.float32)
+    assert np.array_equal(ref.crop(full), oracle.crop(full)[0]) and oracle.crop(full)[0].shape == (20, 30, 3)
+    none = np.full((10, 12, 3), -1, np.float32)
+    assert ref.crop(none).size == 0 and oracle.crop(none)[0].size == 0

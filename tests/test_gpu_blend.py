@@ -136,3 +136,34 @@ def test_cyl_warp_equals_oracle(ctx, oracle, cfg, h, w, hf):
     cv = hip.cyl_warp(ctx, cfg, img, hf)
     got = cv.numpy(); cv.free()
     _compare(got, want, False)
+
+
+@pytest.mark.parametrize("method,proj", [(0, "flat"), (2, "camera")])
+def test_crop_and_u8_output_equal_oracle(ctx, oracle, method, proj):
+    """crop() (lib/imgproc.cc:200-235) and the write_rgb quantisation (lib/imgio.cc:98-113) on the
+    device-resident canvas: same rectangle / same bytes as the oracle computes from that canvas."""
+    cfg = _cfg(ESTIMATE_CAMERA=int(method != 0), TRANS=int(method == 0), ORDERED_INPUT=int(method == 0))
+    views, homos = synth.pano_scene(5, 200, 280, seed=41 + method, proj=proj)
+    views = [v.copy() for v in views]
+    views[3][:60, :90] = -1.0                       # a hole that the rectangle has to avoid
+    cv = hip.blend(ctx, cfg, views, homos, method, 2)
+    full = cv.numpy()
+    want, (wx, wy) = oracle.crop(full)
+    cc, (gx, gy) = cv.crop()
+    got = cc.numpy()
+    assert want.size > 10000 and (gx, gy) == (wx, wy) and np.array_equal(got, want)
+    assert (got >= 0).all()
+    assert np.array_equal(cc.numpy_u8(), oracle.to_u8(want))
+    assert np.array_equal(cv.numpy_u8(), oracle.to_u8(full))
+    cc.free(); cv.free()
+
+
+def test_crop_of_empty_canvas(ctx, oracle):
+    """nothing valid: the reference returns a 0 x 1 image (lib/imgproc.cc:205,225)"""
+    cfg = _cfg(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1)
+    views, homos = synth.pano_scene(2, 64, 80, seed=3, proj="flat")
+    views = [np.full_like(v, -1.0) for v in views]
+    cv = hip.blend(ctx, cfg, views, homos, 0, 1)
+    cc, _ = cv.crop()
+    assert (cc.h, cc.w) == (0, 1)
+    cc.free(); cv.free()
