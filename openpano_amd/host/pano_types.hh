@@ -15,6 +15,9 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <fstream>
+#include <istream>
+#include <ostream>
 #include <limits>
 #include <memory>
 #include <string>
@@ -127,6 +130,9 @@ class Homography {
 			return Vec2D(r.x * denom, r.y * denom);
 		}
 		static Homography I() { Homography r; for (int i = 0; i < 9; ++i) r.data[i] = (i % 4 == 0); return r; }
+		// text form of stitch/homography.hh:154-163 (default stream precision, like the reference)
+		void serialize(std::ostream& os) const { for (int i = 0; i < 8; ++i) os << data[i] << " "; os << data[8]; }
+		static Homography deserialize(std::istream& is) { Homography r; for (int i = 0; i < 9; ++i) is >> r[i]; return r; }
 };
 
 struct MatchInfo {
@@ -135,7 +141,50 @@ struct MatchInfo {
 	float confidence = 0;                          // negative: -#inliers of a rejected pair
 	Homography homo;
 	void reverse() { for (auto& c : match) std::swap(c.first, c.second); }
+	// stitch/match_info.hh:26-50: "confidence homo[9] n  to.x to.y from.x from.y ..."
+	void serialize(std::ostream& os) const {
+		os << confidence << " ";
+		homo.serialize(os);
+		os << " " << match.size();
+		for (auto& p : match) os << " " << p.first.x << " " << p.first.y << " " << p.second.x << " " << p.second.y;
+	}
+	static MatchInfo deserialize(std::istream& is) {
+		MatchInfo ret;
+		is >> ret.confidence;
+		ret.homo = Homography::deserialize(is);
+		int match_size;
+		is >> match_size;
+		ret.match.resize(match_size);
+		for (int i = 0; i < match_size; ++i) { PCC& p = ret.match[i]; is >> p.first.x >> p.first.y >> p.second.x >> p.second.y; }
+		return ret;
+	}
 };
+
+// Stitcher::dump_matchinfo / load_matchinfo (stitch/debug.cc:111-140): the reference's on-disk
+// checkpoint of the match + RANSAC stage ("i j" line, then the serialized MatchInfo; only pairs
+// with positive confidence), usable as a cross-implementation fixture
+inline void dump_matchinfo(const char* fname, const std::vector<std::vector<MatchInfo>>& pairwise_matches) {
+	std::ofstream fout(fname);
+	const int n = (int)pairwise_matches.size();
+	for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+		const MatchInfo& m = pairwise_matches[i][j];
+		if (m.confidence <= 0) continue;
+		fout << i << " " << j << std::endl;
+		m.serialize(fout);
+		fout << std::endl;
+	}
+}
+inline std::vector<std::vector<MatchInfo>> load_matchinfo(const char* fname, int n) {
+	std::vector<std::vector<MatchInfo>> pm(n, std::vector<MatchInfo>(n));
+	std::ifstream fin(fname);
+	int i, j;
+	while (true) {
+		fin >> i >> j;
+		if (fin.eof() || !fin) break;
+		pm[i][j] = MatchInfo::deserialize(fin);
+	}
+	return pm;
+}
 
 // in-memory image reference (the reference's lazy file loading stays with its CLI)
 struct ImageRef {

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <omp.h>
 #include <random>
+#include <sstream>
 
 #include "lib/config.hh"
 #include "lib/mat.h"
@@ -369,6 +370,20 @@ void ref_crop(const float* rgb, int h, int w, int* ch, int* cw, float* out) {
 	Mat32f r = crop(wrap_rgb(rgb, h, w));
 	*ch = r.height(); *cw = r.width();
 	if (out) memcpy(out, r.ptr(), sizeof(float) * (size_t)r.height() * r.width() * 3);
+}
+
+// MatchInfo::serialize (stitch/match_info.hh:26-36): text into buf (cap bytes), returns length
+int ref_matchinfo_serialize(float confidence, const double* homo, const double* pts, int n, char* buf, int cap) {
+	MatchInfo info;
+	info.confidence = confidence;
+	for (int i = 0; i < 9; ++i) info.homo[i] = homo[i];
+	for (int i = 0; i < n; ++i) info.match.emplace_back(Vec2D(pts[4 * i], pts[4 * i + 1]), Vec2D(pts[4 * i + 2], pts[4 * i + 3]));
+	std::ostringstream os;
+	info.serialize(os);
+	std::string t = os.str();
+	if ((int)t.size() + 1 > cap) return -1;
+	memcpy(buf, t.c_str(), t.size() + 1);
+	return (int)t.size();
 }
 
 }	// extern "C"
