@@ -142,6 +142,36 @@ static_assert(((GR + RV - 1) / RV) * (GC + 12) <= 256 && ((GC + RH - 1) / RH) * 
 // rows of the transposed column-pass buffer: NC used + padding for the row pass's tail strip
 __host__ __device__ constexpr int vt_rows(int halo) { return ((GC + RH - 1) / RH) * RH + 2 * halo; }
 
+// N outputs y[r] = sum_k win[r+k] * kw[k], taps accumulated in order k = 0..2C with separate
+// multiply and add (the reference's  tmp += line[i+k] * kernel[k],  gaussian.hh:63-64), two
+// outputs per v_pk_mul_f32 / v_pk_add_f32.  The operand pair of outputs (2j, 2j+1) at tap k is
+// (win[2j+k], win[2j+k+1]): even offsets come from the aligned pairs WA, odd ones from a copy of
+// the window shifted by one element (WB), so that EVERY multiply-add is packed.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int C, int N>
+__device__ __forceinline__ void packed_taps(const float (&win)[N + 2 * C], const float (&kw)[2 * C + 1], float (&out)[N]) {
+	static_assert(N % 2 == 0, "packed_taps: even output count");
+	constexpr int W = N + 2 * C;             // even
+	f32x2 WA[W / 2], WB[W / 2];
+#pragma unroll
+	for (int i = 0; i < W / 2; ++i) { WA[i] = f32x2{win[2 * i], win[2 * i + 1]}; WB[i] = f32x2{win[2 * i + 1], 2 * i + 2 < W ? win[2 * i + 2] : 0.f}; }
+	f32x2 acc[N / 2];
+#pragma unroll
+	for (int j = 0; j < N / 2; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+	for (int k = 0; k < 2 * C + 1; ++k) {
+		const f32x2 kk = f32x2{kw[k], kw[k]};
+#pragma unroll
+		for (int j = 0; j < N / 2; ++j) {
+			const f32x2 w = (k % 2 == 0) ? WA[j + k / 2] : WB[j + (k - 1) / 2];
+			const f32x2 prod = w * kk;
+			acc[j] = acc[j] + prod;
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < N / 2; ++j) { out[2 * j] = acc[j].x; out[2 * j + 1] = acc[j].y; }
+}
+
 // register-blocked passes for kernel half-width C (taps = 2C+1)
 template <int C, int RV>
 __device__ __forceinline__ void vpass_blocked(const float* __restrict__ In, float* __restrict__ VT,
@@ -161,12 +191,19 @@ __device__ __forceinline__ void vpass_blocked(const float* __restrict__ In, floa
 	float kw[2 * C + 1];
 #pragma unroll
 	for (int k = 0; k < 2 * C + 1; ++k) kw[k] = kern[k - C];
+	if constexpr (RV % 2 == 0) {
+		float o[RV];
+		packed_taps<C, RV>(win, kw, o);
 #pragma unroll
-	for (int r = 0; r < RV; ++r) {
-		float tmp = 0.f;
+		for (int r = 0; r < RV; ++r) if (r0 + r < GR) VT[c * PV + r0 + r] = o[r];
+	} else {
 #pragma unroll
-		for (int k = 0; k < 2 * C + 1; ++k) tmp += win[r + k] * kw[k];
-		if (r0 + r < GR) VT[c * PV + r0 + r] = tmp;
+		for (int r = 0; r < RV; ++r) {
+			float tmp = 0.f;
+#pragma unroll
+			for (int k = 0; k < 2 * C + 1; ++k) tmp += win[r + k] * kw[k];
+			if (r0 + r < GR) VT[c * PV + r0 + r] = tmp;
+		}
 	}
 }
 
@@ -186,12 +223,19 @@ __device__ __forceinline__ void hpass_blocked(const float* __restrict__ VT, floa
 	float kw[2 * C + 1];
 #pragma unroll
 	for (int k = 0; k < 2 * C + 1; ++k) kw[k] = kern[k - C];
+	if constexpr (RH % 2 == 0) {
+		float o[RH];
+		packed_taps<C, RH>(win, kw, o);
 #pragma unroll
-	for (int g = 0; g < RH; ++g) {
-		float tmp = 0.f;
+		for (int g = 0; g < RH; ++g) if (g0 + g < GC) G[r * PG + g0 + g] = o[g];
+	} else {
 #pragma unroll
-		for (int k = 0; k < 2 * C + 1; ++k) tmp += win[g + k] * kw[k];
-		if (g0 + g < GC) G[r * PG + g0 + g] = tmp;
+		for (int g = 0; g < RH; ++g) {
+			float tmp = 0.f;
+#pragma unroll
+			for (int k = 0; k < 2 * C + 1; ++k) tmp += win[g + k] * kw[k];
+			if (g0 + g < GC) G[r * PG + g0 + g] = tmp;
+		}
 	}
 }
 
