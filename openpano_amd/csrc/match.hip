@@ -94,7 +94,7 @@ struct MatchState {
 	float* fnext;       // per A row: exact second-min distance
 	int* surv;          // per pair region (res_off .. res_off+ka): A rows that passed the first ratio test
 	int* nsurv;         // per pair
-	int* res;           // per A row: final match column or -1
+	int* mlist;         // accepted matches: [0] = count, then (pair, a, b) triples in arrival order
 	int* slow_fwd; int* slow_rev;   // rows needing a full scan: [0] = count, then (pair, row) pairs
 	int slow_cap;
 	float rr;           // MATCH_REJECT_NEXT_RATIO^2 (matcher.cc:16)
@@ -111,9 +111,13 @@ __device__ __forceinline__ void finish_forward(const MatchState& S, const PairDe
 	} else S.fb[o] = -1;
 }
 // second ratio test (matcher.cc:62)
-__device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDesc& pd, int a, float next_min) {
+__device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDesc& pd, int pair, int a, float next_min) {
 	const long long o = (long long)pd.res_off + a;
-	if (!(S.fmn[o] > S.rr * next_min)) S.res[o] = S.fb[o];
+	if (!(S.fmn[o] > S.rr * next_min)) {
+		const int slot = atomicAdd(&S.mlist[0], 1);        // a row is accepted at most once: slot < total rows
+		int* q = S.mlist + 1 + 3 * (long long)slot;
+		q[0] = pair; q[1] = a; q[2] = S.fb[o];
+	}
 }
 
 // One workgroup = 128 rows of X (4 waves x 32 rows, X fragments resident in VGPRs) against all
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 			const int slot = atomicAdd(&q[0], 1);
 			if (slot < S.slow_cap) { q[1 + 2 * slot] = wk.pair; q[2 + 2 * slot] = a_row; }
 			if (!REV) S.fb[pd.res_off + a_row] = -2;
-		} else if (REV) finish_reverse(S, pd, a_row, next_min);
+		} else if (REV) finish_reverse(S, pd, wk.pair, a_row, next_min);
 		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
 	}
 }
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(64) k_match_slow(MatchState S) {
 		}
 		if (lane == 0) {
 			if (!REV) finish_forward(S, pd, pair, a, mn, next_min, min_idx == 0x7fffffff ? -1 : min_idx);
-			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, a, next_min < f ? next_min : f); }
+			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, pair, a, next_min < f ? next_min : f); }
 		}
 	}
 }
@@ -376,11 +380,14 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
 	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr;
-	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_res = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
+	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_mlist = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
 	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr;
-	int* h_res = (int*)ctx->pinned_scratch(sizeof(int) * nres);     // pinned: the D2H runs at link rate
+	// accepted matches come back as one packed list (count + triples); the first copy takes a
+	// head of kHead entries, which covers the usual few percent of rows, a second one the rest
+	const size_t kHead = std::min<size_t>(nres, 1 << 16);
+	int* h_ml = (int*)ctx->pinned_scratch(sizeof(int) * (1 + 3 * nres));     // pinned: the D2H runs at link rate
 	int rc = OP_OK;
-	if (!h_res) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
+	if (!h_ml) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
 	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
 	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
@@ -389,13 +396,13 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	MCHK(pool_alloc((void**)&d_fb, sizeof(int) * nres));
 	MCHK(pool_alloc((void**)&d_surv, sizeof(int) * nres));
 	MCHK(pool_alloc((void**)&d_nsurv, sizeof(int) * npairs));
-	MCHK(pool_alloc((void**)&d_res, sizeof(int) * nres));
+	MCHK(pool_alloc((void**)&d_mlist, sizeof(int) * (1 + 3 * nres)));
 	MCHK(pool_alloc((void**)&d_slow, sizeof(int) * 2 * (1 + 2 * (size_t)slow_cap)));
 	MCHK(pool_alloc((void**)&d_work, sizeof(WorkItem) * std::max<size_t>(work.size(), 1)));
 	MCHK(pool_alloc((void**)&d_pds, sizeof(PairDesc) * npairs));
 	MCHK(hipMemsetAsync(d_gmax, 0, sizeof(unsigned), st));
 	MCHK(hipMemsetAsync(d_nsurv, 0, sizeof(int) * npairs, st));
-	MCHK(hipMemsetAsync(d_res, 0xff, sizeof(int) * nres, st));
+	MCHK(hipMemsetAsync(d_mlist, 0, sizeof(int), st));
 	MCHK(hipMemsetAsync(d_slow, 0, sizeof(int), st));
 	MCHK(hipMemsetAsync(d_slow + 1 + 2 * (size_t)slow_cap, 0, sizeof(int), st));
 	if (!work.empty()) MCHK(hipMemcpyAsync(d_work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
@@ -408,7 +415,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	if (!work.empty()) {
 		MatchState S;
 		S.desc = fv.desc; S.norms = d_norms; S.gmax_bits = d_gmax; S.pairs = d_pds;
-		S.fb = d_fb; S.fmn = d_fmn; S.fnext = d_fnext; S.surv = d_surv; S.nsurv = d_nsurv; S.res = d_res;
+		S.fb = d_fb; S.fmn = d_fmn; S.fnext = d_fnext; S.surv = d_surv; S.nsurv = d_nsurv; S.mlist = d_mlist;
 		S.slow_fwd = d_slow; S.slow_rev = d_slow + 1 + 2 * (size_t)slow_cap; S.slow_cap = slow_cap;
 		S.rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
 		{
@@ -427,25 +434,40 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 			MCHK(hipGetLastError());
 		}
 	}
-	MCHK(hipMemcpyAsync(h_res, d_res, sizeof(int) * nres, hipMemcpyDeviceToHost, st));
-	MCHK(hipStreamSynchronize(st));
-	resolve_profile(ctx);
-	for (int p = 0; p < npairs; ++p) {
-		const PairDesc& pd = pds[p];
-		std::vector<int>& v = m->pairs[p];
-		if (!pd.rev) {                       // rows ascend in a: already sorted by (first, second)
-			for (int a = 0; a < pd.ka; ++a) { const int b = h_res[pd.res_off + a]; if (b >= 0) { v.push_back(a); v.push_back(b); } }
-		} else {                             // pairs are <b, a> (matcher.cc:68-69): sort by b
-			std::vector<std::pair<int, int>> t;
-			for (int a = 0; a < pd.ka; ++a) { const int b = h_res[pd.res_off + a]; if (b >= 0) t.emplace_back(b, a); }
-			std::sort(t.begin(), t.end());
-			for (auto& q : t) { v.push_back(q.first); v.push_back(q.second); }
+	h_ml[0] = 0;
+	if (!work.empty()) {
+		MCHK(hipMemcpyAsync(h_ml, d_mlist, sizeof(int) * (1 + 3 * kHead), hipMemcpyDeviceToHost, st));
+		MCHK(hipStreamSynchronize(st));
+		if ((size_t)h_ml[0] > kHead) {
+			MCHK(hipMemcpyAsync(h_ml + 1 + 3 * kHead, d_mlist + 1 + 3 * kHead, sizeof(int) * 3 * ((size_t)h_ml[0] - kHead), hipMemcpyDeviceToHost, st));
+			MCHK(hipStreamSynchronize(st));
 		}
-		m->total += (int64_t)(v.size() / 2);
+	} else MCHK(hipStreamSynchronize(st));
+	resolve_profile(ctx);
+	{
+		const int nm = h_ml[0];
+		std::vector<int> cnt(npairs, 0);
+		for (int e = 0; e < nm; ++e) ++cnt[h_ml[1 + 3 * e]];
+		for (int p = 0; p < npairs; ++p) m->pairs[p].reserve(2 * (size_t)cnt[p]);
+		for (int e = 0; e < nm; ++e) {
+			const int* q = h_ml + 1 + 3 * (size_t)e;
+			std::vector<int>& v = m->pairs[q[0]];
+			if (pds[q[0]].rev) { v.push_back(q[2]); v.push_back(q[1]); }        // pairs are <b, a> (matcher.cc:68-69)
+			else { v.push_back(q[1]); v.push_back(q[2]); }
+		}
+		for (int p = 0; p < npairs; ++p) {         // arrival order is arbitrary: sort by (first, second)
+			std::vector<int>& v = m->pairs[p];
+			const size_t k = v.size() / 2;
+			if (k > 1) {
+				std::pair<int, int>* pp = reinterpret_cast<std::pair<int, int>*>(v.data());
+				std::sort(pp, pp + k);
+			}
+			m->total += (int64_t)k;
+		}
 	}
 done:
 	pool_free(d_norms); pool_free(d_gmax); pool_free(d_fmn); pool_free(d_fnext); pool_free(d_fb); pool_free(d_surv);
-	pool_free(d_nsurv); pool_free(d_res); pool_free(d_slow); pool_free(d_work); pool_free(d_pds);
+	pool_free(d_nsurv); pool_free(d_mlist); pool_free(d_slow); pool_free(d_work); pool_free(d_pds);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
 	*out = m;
