@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_norms(const float* desc, long long tota
 }
 
 // running top-NK (descending score); the common case is the single rejecting compare
-constexpr int NK = 8;
+constexpr int NK = 4;
 __device__ __forceinline__ void topk_insert(float (&ts)[NK], int (&ti)[NK], float s, int idx) {
 	if (!(s > ts[NK - 1])) return;
 #pragma unroll
