@@ -38,7 +38,7 @@ struct DescLds {
 };
 
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
-		const long long* img_offset, long long total, float* desc, double* coor, double* real) {
+		const long long* img_offset, long long cap, float* desc, double* coor, double* real) {
 	__shared__ DescLds S;
 	const int lane = threadIdx.x;
 	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
@@ -46,6 +46,8 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 	const float nbin_per_rad = 8 / pi2;
 	const int cell = lane >> 2, hj = lane & 3;
 
+	long long total = img_offset[p.n];                 // device-side count (k_image_offsets)
+	total = total < cap ? total : cap;                 // speculative capacity: the host re-runs on overflow
 	for (long long kk = blockIdx.x; kk < total; kk += gridDim.x) {
 		int img = 0;
 		while (img + 1 < p.n && kk >= img_offset[img + 1]) ++img;
@@ -218,9 +220,9 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 }	// namespace
 
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset,
-		long long total, float* desc, double* coor, double* real, hipStream_t st) {
-	if (total <= 0) return hipSuccess;
-	const int grid = (int)(total < 32768 ? total : 32768);
-	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, total, desc, coor, real);
+		long long cap, float* desc, double* coor, double* real, hipStream_t st) {
+	if (cap <= 0) return hipSuccess;
+	const int grid = (int)(cap < 32768 ? cap : 32768);          // wavefronts beyond the device-side count exit at once
+	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, cap, desc, coor, real);
 	return hipGetLastError();
 }

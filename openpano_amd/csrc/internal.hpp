@@ -143,9 +143,12 @@ hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const 
 		float* dirs /* n x cap x 36 */, int* ndirs /* n x cap */, hipStream_t st);
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const long long* img_offset /* n+1, device */,
-		KeyPoint* oriented, hipStream_t st);
+		KeyPoint* oriented, long long oriented_cap, hipStream_t st);
+// device-side exclusive prefix of the per-image counts: img_offset[0..n], img_offset[n] = total
+hipError_t launch_image_offsets(const SiftPlan& p, const int* per_image, long long* img_offset, hipStream_t st);
 hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
 		int* per_image /* n */, hipStream_t st);
+// the descriptor count is read on the device (img_offset[n]); cap = capacity of the output buffers
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset /* n+1 device */,
-		long long total, float* desc, double* coor, double* real, hipStream_t st);
+		long long cap, float* desc, double* coor, double* real, hipStream_t st);
 hipError_t launch_debug_math(int which, const float* x, const float* y, int n, float* out, hipStream_t st);

@@ -342,9 +342,26 @@ __global__ void __launch_bounds__(256) k_count_oriented(const int* refined_count
 	if (threadIdx.x == 0) per_image[img] = s_sum[0];
 }
 
+// exclusive prefix of the per-image descriptor counts -> img_offset[0..n] (img_offset[n] = total);
+// one workgroup, images in index order.  Keeps the host out of the middle of the pipeline.
+__global__ void __launch_bounds__(256) k_image_offsets(const int* __restrict__ per_image, int n, long long* __restrict__ img_offset) {
+	__shared__ long long s_part[256];
+	// each thread sums a contiguous chunk, then a serial pass over the 256 partials (n is tiny)
+	const int chunk = (n + 255) / 256;
+	const int b = threadIdx.x * chunk, e = b + chunk < n ? b + chunk : n;
+	long long acc = 0;
+	for (int i = b; i < e; ++i) acc += per_image[i];
+	s_part[threadIdx.x] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) { long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = s_part[t]; s_part[t] = run; run += v; } img_offset[n] = run; }
+	__syncthreads();
+	long long run = s_part[threadIdx.x];
+	for (int i = b; i < e; ++i) { img_offset[i] = run; run += per_image[i]; }
+}
+
 // expansion refined -> oriented in (refined order, peak order): OrientationAssign::work (:22-32)
 __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
-		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented) {
+		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, long long oriented_cap) {
 	__shared__ int s_scan[256];
 	__shared__ int s_base;
 	const int img = blockIdx.x;
@@ -368,7 +385,8 @@ __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined
 			const float* d = dirs + ((long long)img * cap + i) * ORI_BINS;
 			for (int j = 0; j < cnt; ++j) {
 				kp.dir = d[j]; kp.src = i;
-				oriented[img_offset[img] + excl + j] = kp;
+				const long long slot = img_offset[img] + excl + j;
+				if (slot < oriented_cap) oriented[slot] = kp;       // speculative capacity: the host re-runs on overflow
 			}
 		}
 		__syncthreads();
@@ -408,7 +426,12 @@ hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, in
 }
 
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, hipStream_t st) {
-	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, img_offset, oriented);
+		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, long long oriented_cap, hipStream_t st) {
+	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, img_offset, oriented, oriented_cap);
+	return hipGetLastError();
+}
+
+hipError_t launch_image_offsets(const SiftPlan& p, const int* per_image, long long* img_offset, hipStream_t st) {
+	hipLaunchKernelGGL(k_image_offsets, dim3(1), dim3(256), 0, st, per_image, p.n, img_offset);
 	return hipGetLastError();
 }

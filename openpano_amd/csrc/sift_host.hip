@@ -33,6 +33,7 @@ struct DevBuf {
 struct Workspace {
 	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, offsets, oriented;
 	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch for counts/offsets
+	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
 		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); offsets.release(); oriented.release();
@@ -221,34 +222,42 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, st));
 	  HIPCHK(launch_count_oriented(plan, d_refined_count, cap, (const int*)W.ndirs.p, d_oriented_count, st)); }
 
-	// pinned scratch regions: [0,8n) source table | [16n,28n) counts | [32n, 40n+8) offsets
-	int* h_counts = (int*)((char*)W.pinned + 16 * (size_t)n);
-	HIPCHK(hipMemcpyAsync(h_counts, W.counts.p, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
-	HIPCHK(hipStreamSynchronize(st));
+	// The descriptor count is only known on the device at this point.  Instead of a round trip,
+	// the output buffers get a capacity predicted from the previous call of this context (x1.25,
+	// at least 2048 per image), offsets are computed on the device and the remaining stages are
+	// enqueued right away; ONE synchronisation at the end returns the counts, and a batch that
+	// outgrew the prediction re-runs its last two stages with exact sizes.
+	HIPCHK(launch_image_offsets(plan, d_oriented_count, (long long*)W.offsets.p, st));
+	long long capK = std::max<long long>((long long)n * 2048, W.last_total + W.last_total / 4);
+	int* h_counts = (int*)((char*)W.pinned + 16 * (size_t)n);                  // pinned: [16n, 28n) counts
+	long long* h_total = (long long*)((char*)W.pinned + 32 * (size_t)n);     // pinned: [32n, ..) total
+	long long total = 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)capK));
+		HIPCHK(pool_alloc((void**)&res.desc, sizeof(float) * 128 * (size_t)capK));
+		HIPCHK(pool_alloc((void**)&res.coor, sizeof(double) * 2 * (size_t)capK));
+		HIPCHK(pool_alloc((void**)&res.real, sizeof(double) * 2 * (size_t)capK));
+		{ ProfScope ps(ctx, "orientation");
+		  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
+					(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, capK, st)); }
+		{ ProfScope ps(ctx, "sift descriptor");
+		  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, capK, res.desc, res.coor, res.real, st)); }
+		HIPCHK(hipMemcpyAsync(h_counts, W.counts.p, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipMemcpyAsync(h_total, (const long long*)W.offsets.p + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		total = *h_total;
+		if (total <= capK) break;
+		pool_free(res.desc); pool_free(res.coor); pool_free(res.real); res.desc = nullptr; res.coor = nullptr; res.real = nullptr;
+		capK = total;                                   // exact size, second and last attempt
+	}
+	resolve_profile(ctx);
+	W.last_total = total;
 	std::vector<int> raw_count(h_counts, h_counts + n), refined_count(h_counts + n, h_counts + 2 * n);
 	res.counts.assign(h_counts + 2 * n, h_counts + 3 * n);
+	res.total = total;
 	for (int i = 0; i < n; ++i)
 		if (raw_count[i] > cap)
 			OP_FAIL(OP_ERR_CAPACITY, "raw extrema list overflow: " + std::to_string(raw_count[i]) + " > " + std::to_string(cap));
-	long long* h_off = (long long*)((char*)W.pinned + 32 * (size_t)n);
-	long long total = 0;
-	std::vector<long long> offs(n + 1);
-	for (int i = 0; i < n; ++i) { offs[i] = total; total += res.counts[i]; }
-	offs[n] = total;
-	memcpy(h_off, offs.data(), sizeof(long long) * (n + 1));
-	HIPCHK(hipMemcpyAsync(W.offsets.p, h_off, sizeof(long long) * (n + 1), hipMemcpyHostToDevice, st));
-	res.total = total;
-	HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(pool_alloc((void**)&res.desc, sizeof(float) * 128 * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(pool_alloc((void**)&res.coor, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
-	HIPCHK(pool_alloc((void**)&res.real, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
-	{ ProfScope ps(ctx, "orientation");
-	  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
-				(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, st)); }
-	{ ProfScope ps(ctx, "sift descriptor");
-	  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, total, res.desc, res.coor, res.real, st)); }
-	HIPCHK(hipStreamSynchronize(st));     // h_off (pinned) consumed; results ready
-	resolve_profile(ctx);
 
 	if (keep) {
 		keep->cap = cap;
