@@ -55,7 +55,9 @@ __global__ void __launch_bounds__(256) k_norms(const float* desc, long long tota
 	if (s == s) atomicMax(gmax_bits, __float_as_uint(s));     // a NaN descriptor must not poison the margin of every row
 }
 
-// running top-NK (descending score); the common case is the single rejecting compare
+// running top-NK (descending score); the common case is the single rejecting compare.  NK = 4:
+// the insertion network runs for the whole wave whenever ANY lane inserts (most steps), so it is
+// kept short; rows whose 4 entries all tie within the error margin go to the exact full scan.
 constexpr int NK = 4;
 __device__ __forceinline__ void topk_insert(float (&ts)[NK], int (&ti)[NK], float s, int idx) {
 	if (!(s > ts[NK - 1])) return;

@@ -75,6 +75,24 @@ def main():
                         n1=np.int32(len(sa.desc)), n2=np.int32(len(sb.desc)))
     print("match_ab", len(sa.desc), len(sb.desc), "->", len(pairs))
     blend_case(ref)
+    ransac_case(ref, sa, sb, pairs)
+
+
+def ransac_case(ref, sa, sb, pairs):
+    """TransformEstimation::get_transform of the reference (mt19937 seed injected through the
+    random_device seam of oracle/ref_driver.cc) on the golden match list of views a/b (320x240):
+    homography mode and, with CYLINDER=1, the 7-point affine mode."""
+    ca = (sa.coor - 0.5) * np.array([320.0, 240.0]); cb = (sb.coor - 0.5) * np.array([320.0, 240.0])   # feature.cc:23-26
+    out = dict(match=pairs, coor_a=ca, coor_b=cb, shape=np.array([320, 240], np.int32))
+    for mode, cfgkv in (("homo", dict()), ("affine", dict(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1))):
+        ref.set_config(**cfgkv)
+        for seed in (7, 20240917):
+            r = ref.ransac(pairs, ca, cb, (320, 240), (320, 240), seed)
+            out[f"{mode}_{seed}_ok"] = np.int32(r["ok"]); out[f"{mode}_{seed}_conf"] = np.float32(r["confidence"])
+            out[f"{mode}_{seed}_homo"] = r["homo"]; out[f"{mode}_{seed}_pts"] = r["inlier_pts"]
+            print("ransac", mode, seed, r["ok"], r["confidence"], len(r["inlier_pts"]))
+        ref.set_config(CYLINDER=0, ESTIMATE_CAMERA=1, ORDERED_INPUT=0)
+    np.savez_compressed(os.path.join(HERE, "ransac_ab.npz"), **out)
 
 
 def blend_case(ref):

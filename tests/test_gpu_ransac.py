@@ -71,3 +71,21 @@ def test_affine_and_degenerate_pairs(ctx, oracle, cfg):
     assert res[0]["ok"] and res[0]["homo"][2, 0] == 0 and res[0]["homo"][2, 2] == 1
     assert not res[1]["ok"] and not res[2]["ok"] and not res[3]["ok"]
     mh.free(); mh2.free(); f.free()
+
+
+def test_ransac_golden_fixture(ctx, cfg):
+    """Committed output of the REFERENCE's TransformEstimation (tests/golden/ransac_ab.npz)."""
+    import os
+    from openpano_amd import hip
+    from openpano_amd.config import PanoConfig
+    from test_oracle_golden import _ransac_golden_check
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ransac_ab.npz"))
+    cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+
+    def run(m, ca, cb, shape, seed, affine):
+        f = hip.Features.from_host(ctx, [np.zeros((len(ca), 128), np.float32), np.zeros((len(cb), 128), np.float32)], [ca, cb])
+        mh = hip.Matches.from_host([m])
+        r = hip.ransac_pairs(ctx, cyl if affine else cfg, f, mh, [(0, 1)], [shape, shape], seeds=[seed])[0]
+        mh.free(); f.free()
+        return r
+    _ransac_golden_check(run, g)

@@ -87,3 +87,28 @@ def test_blend_oracle_matches_golden():
         got, meta = Oracle(cfg).blend(views, z["homos"], 2, int(z["identity_idx"]), cfg)
         assert np.array_equal(got, z["canvas_" + key]), key
         assert np.array_equal(meta["geom"], z["geom"]) and np.array_equal(meta["ranges"], z["ranges"])
+
+
+def _ransac_golden_check(run, g):
+    """run(match, ca, cb, shape, seed, affine) -> dict(ok, confidence, homo, inliers)"""
+    m, ca, cb = g["match"], g["coor_a"], g["coor_b"]
+    shape = tuple(int(v) for v in g["shape"])
+    for mode in ("homo", "affine"):
+        for seed in (7, 20240917):
+            r = run(m, ca, cb, shape, seed, mode == "affine")
+            assert bool(r["ok"]) == bool(g[f"{mode}_{seed}_ok"]), (mode, seed)
+            assert np.float32(r["confidence"]) == g[f"{mode}_{seed}_conf"], (mode, seed)
+            if r["ok"]:
+                pts = np.array([[ca[m[k][0]][0], ca[m[k][0]][1], cb[m[k][1]][0], cb[m[k][1]][1]] for k in r["inliers"]])
+                assert np.array_equal(pts, g[f"{mode}_{seed}_pts"]), (mode, seed)
+                # the reference solves the DLT with JacobiSVD, this side with Givens QR: equal to rounding
+                assert np.allclose(r["homo"], g[f"{mode}_{seed}_homo"], rtol=1e-7, atol=1e-9), (mode, seed)
+
+
+def test_ransac_oracle_matches_golden(oracle):
+    """oracle/ransac_oracle.c against the committed output of the reference's own
+    TransformEstimation::get_transform (seed-injected); runs anywhere."""
+    from openpano_amd.config import PanoConfig
+    g = np.load(os.path.join(HERE, "golden", "ransac_ab.npz"))
+    cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+    _ransac_golden_check(lambda m, ca, cb, sh, seed, aff: oracle.ransac(m, ca, cb, sh, sh, seed, cfg=cyl if aff else None), g)
