@@ -167,7 +167,7 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
             cv = hip.blend(ctx, bcfg, inputs, homos, 2, n // 2)
             hw = (cv.h, cv.w); cv.free()
         torch.cuda.synchronize(); t = time.perf_counter() - t0
-        prof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith(("blend", "multiband"))}
+        prof = {k: v[0] / steps for k, v in ctx.profile().items() if k.startswith(("blend", "multiband"))}
         ctx.set_profiling(False)
         alg = 12.0 * H * W * n + 12.0 * hw[0] * hw[1]            # every source pixel once + canvas write
         kms = sum(prof.values())
@@ -265,7 +265,7 @@ def main():
 
     # ---------------- roofline of the dominant kernel (HIP events, this rank) ----------------
     P, wh, ww = pyramid_pixels(cfg, H, W)
-    stage_ms = {k: v[0] / max(v[1], 1) for k, v in prof.items()}
+    stage_ms = {k: v[0] / max(args.steps, 1) for k, v in prof.items()}       # device time per batch (a label may bracket several launches)
     dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
     # algorithmic HBM bytes per launch (DESIGN.md "kernels"), per image:
     alg = {

@@ -47,7 +47,7 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
         mh.free()
     barrier()
     t = time.perf_counter() - t0
-    prof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith("matcher")}
+    prof = {k: v[0] / steps for k, v in ctx.profile().items() if k.startswith("matcher")}
     ctx.set_profiling(False)
     tt = torch.tensor([t], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(len(mine)), float(nmatch), flops], dtype=torch.float64, device=dev)
@@ -80,7 +80,7 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
         for _ in range(rsteps):
             hip.ransac_pairs_summary(ctx, cfg, gfeats, mh, mine, shapes, base_seed=1)
         torch.cuda.synchronize(); tr = time.perf_counter() - t0
-        rprof = {k: v[0] / max(v[1], 1) for k, v in ctx.profile().items() if k.startswith("ransac")}
+        rprof = {k: v[0] / rsteps for k, v in ctx.profile().items() if k.startswith("ransac")}
         ctx.set_profiling(False)
         mh.free()
         res["ransac"] = {"image_pairs_per_s": len(mine) * rsteps / tr, "ms_per_step": tr / rsteps * 1e3, "pairs": len(mine),
