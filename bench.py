@@ -170,8 +170,17 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
         prof = {k: v[0] / steps for k, v in ctx.profile().items() if k.startswith(("blend", "multiband"))}
         ctx.set_profiling(False)
         alg = 12.0 * H * W * n + 12.0 * hw[0] * hw[1]            # every source pixel once + canvas write
+        if bcfg.MULTIBAND > 0:                                   # ... + 2*16*sum(ROI) per level (WeightedPixel planes)
+            g, _, ranges = hip.blend_prepare(bcfg, [(W, H)] * n, homos, 2, n // 2)
+            roi = 0
+            for r in ranges:
+                x0 = int((r[0] - g.proj_min[0]) / g.resolution[0]); y0 = int((r[1] - g.proj_min[1]) / g.resolution[1])
+                x1 = int((r[2] - g.proj_min[0]) / g.resolution[0]); y1 = int((r[3] - g.proj_min[1]) / g.resolution[1])
+                roi += (x1 - x0 + 1) * (y1 - y0 + 1)
+            alg += 2.0 * 16 * roi * bcfg.MULTIBAND
+            res_roi = roi
         kms = sum(prof.values())
-        res[key] = {"ms_per_blend": t / steps * 1e3, "canvas": [hw[0], hw[1]], "output_mpix_per_s": hw[0] * hw[1] * steps / t / 1e6,
+        res[key] = {"ms_per_blend": t / steps * 1e3, "canvas": [hw[0], hw[1]], "roi_pixels": (res_roi if bcfg.MULTIBAND > 0 else None), "output_mpix_per_s": hw[0] * hw[1] * steps / t / 1e6,
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()},
                     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else None, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else None,

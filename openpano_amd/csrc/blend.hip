@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) k_mb_weight_map(const BlendImg* __restric
 // replicate borders, sequential fp32 multiply-add in tap order on all 4 channels ----
 struct BlurTaps { int center; float k[2 * OP_MAX_KCENTER + 1]; };
 
-template <bool COLS>
+// CT > 0: half-width known at compile time (6 and 9 for the shipped window factor): the taps are
+// unrolled and all loads of a pixel are in flight together; CT == 0: any half-width.
+template <bool COLS, int CT>
 __global__ void __launch_bounds__(256) k_mb_blur(const BlendImg* __restrict__ imgs, BlurTaps taps,
 		const float4* __restrict__ src, float4* __restrict__ dst) {
 	const BlendImg& im = imgs[blockIdx.y];
@@ -190,13 +192,27 @@ __global__ void __launch_bounds__(256) k_mb_blur(const BlendImg* __restrict__ im
 	const int i = (int)(e / im.rw), j = (int)(e % im.rw);
 	const float4* base = src + im.roi_off;
 	float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-	const int C = taps.center;
-	for (int k = -C; k <= C; ++k) {
-		float4 v;
-		if (COLS) { int ii = i + k; ii = ii < 0 ? 0 : (ii > im.rh - 1 ? im.rh - 1 : ii); v = base[(long long)ii * im.rw + j]; }
-		else { int jj = j + k; jj = jj < 0 ? 0 : (jj > im.rw - 1 ? im.rw - 1 : jj); v = base[(long long)i * im.rw + jj]; }
-		const float kv = taps.k[k + C];
-		t.w += v.w * kv; t.x += v.x * kv; t.y += v.y * kv; t.z += v.z * kv;
+	if (CT > 0) {
+		float4 v[2 * (CT > 0 ? CT : 1) + 1];
+#pragma unroll
+		for (int k = -CT; k <= CT; ++k) {
+			if (COLS) { int ii = i + k; ii = ii < 0 ? 0 : (ii > im.rh - 1 ? im.rh - 1 : ii); v[k + CT] = base[(long long)ii * im.rw + j]; }
+			else { int jj = j + k; jj = jj < 0 ? 0 : (jj > im.rw - 1 ? im.rw - 1 : jj); v[k + CT] = base[(long long)i * im.rw + jj]; }
+		}
+#pragma unroll
+		for (int k = 0; k <= 2 * CT; ++k) {
+			const float kv = taps.k[k];
+			t.w += v[k].w * kv; t.x += v[k].x * kv; t.y += v[k].y * kv; t.z += v[k].z * kv;
+		}
+	} else {
+		const int C = taps.center;
+		for (int k = -C; k <= C; ++k) {
+			float4 v;
+			if (COLS) { int ii = i + k; ii = ii < 0 ? 0 : (ii > im.rh - 1 ? im.rh - 1 : ii); v = base[(long long)ii * im.rw + j]; }
+			else { int jj = j + k; jj = jj < 0 ? 0 : (jj > im.rw - 1 ? im.rw - 1 : jj); v = base[(long long)i * im.rw + jj]; }
+			const float kv = taps.k[k + C];
+			t.w += v.w * kv; t.x += v.x * kv; t.y += v.y * kv; t.z += v.z * kv;
+		}
 	}
 	dst[im.roi_off + e] = t;
 }
@@ -602,9 +618,16 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 				if (gauss_taps((float)(std::sqrt(level * 2 + 1.0) * 4), cfg->GAUSS_WINDOW_FACTOR, taps) != 0) {
 					pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
 				}
-				hipLaunchKernelGGL(k_mb_blur<true>, rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
-				BCHK(hipGetLastError());
-				hipLaunchKernelGGL(k_mb_blur<false>, rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
+				if (taps.center == 6) {
+					hipLaunchKernelGGL((k_mb_blur<true, 6>), rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
+					hipLaunchKernelGGL((k_mb_blur<false, 6>), rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
+				} else if (taps.center == 9) {
+					hipLaunchKernelGGL((k_mb_blur<true, 9>), rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
+					hipLaunchKernelGGL((k_mb_blur<false, 9>), rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
+				} else {
+					hipLaunchKernelGGL((k_mb_blur<true, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
+					hipLaunchKernelGGL((k_mb_blur<false, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
+				}
 				BCHK(hipGetLastError());
 			}
 			{ ProfScope ps(ctx, "multiband band");
