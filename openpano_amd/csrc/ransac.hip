@@ -140,14 +140,25 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 			const int v = base + lane < 624 ? (int)rd[base + lane] : 0;
 			const int lim = 624 - base < 64 ? 624 - base : 64;
 			if (m <= 64) {
-				for (int i = 0; i < lim && K < iters; ++i) {
+				// branch-free scalar chain: membership, insertion and sample completion are bit
+				// operations on wave-uniform values; the lanes learn afterwards which of the 64 draws
+				// were accepted (bit i of acc) and compact them into the staging buffer in one step.
+				// Draws past the last hypothesis are dropped at the flush below.
+				unsigned long long acc = 0ULL;
+#pragma unroll 16
+				for (int i = 0; i < 64; ++i) {
 					const int r = __builtin_amdgcn_readlane(v, i);
-					if ((selmask >> r) & 1ULL) continue;                 // already selected (:73-75)
-					selmask |= 1ULL << r;
-					if (lane == i) ob[cnt] = (unsigned short)v;
-					++cnt;
-					if (++t == ns) { t = 0; ++K; selmask = 0ULL; }
+					const unsigned long long isnew = (i < lim) ? (~(selmask >> r) & 1ULL) : 0ULL;     // already selected? (:73-75)
+					selmask |= isnew << r;
+					acc |= isnew << i;
+					t += (int)isnew;
+					const bool done = t == ns;
+					selmask = done ? 0ULL : selmask;
+					t = done ? 0 : t;
+					K += done ? 1 : 0;
 				}
+				if ((acc >> lane) & 1ULL) ob[cnt + __popcll(acc & ((1ULL << lane) - 1ULL))] = (unsigned short)v;
+				cnt += __popcll(acc);
 			} else {
 				unsigned long long eq[7];                                // bit l of eq[d-1]: draw l == draw l+d
 #pragma unroll
@@ -180,7 +191,7 @@ __global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restric
 		__syncthreads();
 		for (int i = lane; i < cnt; i += 64) {           // accepted draw number -> (hypothesis, slot)
 			const int a = accepted + i;
-			sp[(a / ns) * 8 + a % ns] = ob[i];
+			if (a / ns < iters) sp[(a / ns) * 8 + a % ns] = ob[i];
 		}
 		accepted += cnt;
 	}
