@@ -364,11 +364,12 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	const int iters = cfg->RANSAC_ITERATIONS;
 	if (iters <= 0 || iters > 65536) { delete R; OP_FAIL(OP_ERR_UNSUPPORTED, "RANSAC_ITERATIONS must be in [1, 65536]"); }
 
-	std::unique_ptr<HostScope> hs(new HostScope(ctx, "ransac gather points (host)"));
+	std::unique_ptr<HostScope> hs(new HostScope(ctx, "ransac upload + launch (host)"));
 	std::vector<double> coor((size_t)std::max<long long>(total, 1) * 2);
 	if (total) HIPCHK(hipMemcpyAsync(coor.data(), op_features_coor_device(f), sizeof(double) * 2 * total, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 
+	// pass 1: what the sampling kernel needs (match counts, sample geometry) -- no coordinates yet
 	std::vector<PairHost> ph(npairs);
 	std::vector<PairArgs> pa(npairs);
 	long long pts_total = 0;
@@ -382,23 +383,16 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		h.kp2 = coor.data() + fv.offsets[j] * 2; h.nk2 = fv.counts[j];
 		h.s1 = Shape{shapes_wh[2 * i], shapes_wh[2 * i + 1]}; h.s2 = Shape{shapes_wh[2 * j], shapes_wh[2 * j + 1]};
 		if (h.m > 65535) { delete R; OP_FAIL(OP_ERR_CAPACITY, "more than 65535 matches in one pair"); }
-		h.pts.resize((size_t)h.m * 4);
-		for (int k = 0; k < h.m; ++k) {
-			const int a = h.match[2 * k], b = h.match[2 * k + 1];
-			h.pts[4 * k] = h.kp1[2 * a]; h.pts[4 * k + 1] = h.kp1[2 * a + 1];
-			h.pts[4 * k + 2] = h.kp2[2 * b]; h.pts[4 * k + 3] = h.kp2[2 * b + 1];
-		}
 		// ransac_inlier_thres (float) and INLIER_DIST = sqr(float) (transform_estimate.cc:46,133)
 		const float thres = (float)((h.s1.w + h.s1.h) * 0.5 / 800 * cfg->RANSAC_INLIER_THRES);
 		const float inlier_dist = thres * thres;
 		pa[p] = PairArgs{(int)pts_total, h.m, affine ? 1 : 0, nsample, (double)inlier_dist, (long long)p * iters * 8};
 		pts_total += h.m;
 	}
-		// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
+	// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
 	std::vector<unsigned> h_seeds(npairs);
 	for (int p = 0; p < npairs; ++p) h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
 	std::vector<double> pts_flat((size_t)std::max<long long>(pts_total, 1) * 4);
-	for (int p = 0; p < npairs; ++p) if (ph[p].m) std::memcpy(pts_flat.data() + (size_t)pa[p].pts_off * 4, ph[p].pts.data(), sizeof(double) * 4 * ph[p].m);
 
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
 	PairArgs* d_pa = nullptr; double* d_pts = nullptr; unsigned short* d_samp = nullptr; int* d_counts = nullptr; int2* d_best = nullptr;
@@ -412,15 +406,28 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	RCHK(pool_alloc((void**)&d_samp, sizeof(unsigned short) * (size_t)npairs * iters * 8));
 	RCHK(pool_alloc((void**)&d_seeds, sizeof(unsigned) * npairs));
 	RCHK(pool_alloc((void**)&d_bsamp, sizeof(unsigned short) * 8 * npairs));
-	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
 	RCHK(pool_alloc((void**)&d_counts, sizeof(int) * (size_t)npairs * iters));
 	RCHK(pool_alloc((void**)&d_best, sizeof(int2) * npairs));
+	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
 	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
+	{ ProfScope ps2(ctx, "ransac mt19937 samples");
+	  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(64), 0, st, d_pa, d_seeds, iters, d_samp);
+	  RCHK(hipGetLastError()); }
+	// pass 2, overlapped with the (latency-bound) sampling kernel: gather the matched point pairs
+	hs.reset(); hs.reset(new HostScope(ctx, "ransac gather points (host)"));
+	host_parallel_for(npairs, [&](int p) {
+		PairHost& h = ph[p];
+		h.pts.resize((size_t)h.m * 4);
+		for (int k = 0; k < h.m; ++k) {
+			const int a = h.match[2 * k], b = h.match[2 * k + 1];
+			h.pts[4 * k] = h.kp1[2 * a]; h.pts[4 * k + 1] = h.kp1[2 * a + 1];
+			h.pts[4 * k + 2] = h.kp2[2 * b]; h.pts[4 * k + 3] = h.kp2[2 * b + 1];
+		}
+		if (h.m) std::memcpy(pts_flat.data() + (size_t)pa[p].pts_off * 4, h.pts.data(), sizeof(double) * 4 * h.m);
+	});
+	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
 	RCHK(hipMemcpyAsync(d_pts, pts_flat.data(), sizeof(double) * pts_flat.size(), hipMemcpyHostToDevice, st));
 	{
-		{ ProfScope ps2(ctx, "ransac mt19937 samples");
-		  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(64), 0, st, d_pa, d_seeds, iters, d_samp);
-		  RCHK(hipGetLastError()); }
 		ProfScope ps(ctx, "ransac hypotheses");
 		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, npairs), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts);
 		RCHK(hipGetLastError());
