@@ -39,10 +39,14 @@ class _Reader:
         return a
 
 
-def test_stitch_demo(tmp_path, oracle):
+# (n, h, w): a small case, and BASELINE configs 2 and 3 restated (ordered inputs)
+DEMO_CASES = [(4, 240, 320, 5), (11, 400, 600, 22), (13, 1112, 1500, 33)]
+
+
+@pytest.mark.parametrize("n,h,w,seed", DEMO_CASES, ids=["small", "config2_11x600x400", "config3_13x1500x1112"])
+def test_stitch_demo(tmp_path, oracle, n, h, w, seed):
     assert os.path.exists(DEMO), "build it: make -C openpano_amd/csrc"
-    n, h, w = 4, 240, 320
-    views = synth.image_set(n, h, w, seed=5, overlap=0.5)
+    views = synth.image_set(n, h, w, seed=seed, overlap=0.5)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
         f.write(struct.pack("<3i", n, h, w))
