@@ -5,33 +5,31 @@
 // (feature/feature.cc:20-28).
 //
 // Bit-exactness: the reference accumulates hist[bin] += w in window order (xx outer, yy inner)
-// in fp32, so the summation ORDER is part of the result.  Structure per keypoint:
-//   1a  all 64 lanes test window samples (bounds, circle, rotated bin range), 64 per round;
-//   1b  surviving samples are compacted IN ORDER into LDS records (weights of the 2x2 spatial
-//       cells, orientation fraction) -- the expensive part (expf, gathers) runs on survivors only;
-//   1c  per spatial cell an ordered list of the records that touch it is built with wave
-//       ballots (16 ballots per 64 records);
-//   2   lane (cell, hj) walks its cell's list in order and adds the record's contribution to
-//       the orientation bins hj and hj+4 it owns.  A non-matching orientation adds +0.0f, which
-//       is exact, so every bin sees exactly the reference's sequence of fp32 additions.
-// Records are flushed through 1c/2 whenever an LDS buffer would overflow, so any window size
-// is handled with the same ordering guarantee.
+// in fp32, so the summation ORDER of every one of the 128 bins is part of the result.
+// Structure per keypoint (one wavefront):
+//   1a  all 64 lanes run the cheap window tests (bounds, circle, rotated bin range) in the
+//       reference's sample order; survivors are queued IN ORDER (wave ballot ranks);
+//   1b  dense batches of 64 queued survivors: gradient magnitude / orientation on the Gaussian
+//       plane, weight, and the <= 8 trilinear contributions (bin, value) of each sample
+//       (sift.cc:48-67) -- in registers;
+//   2   a stable counting sort of the batch's contributions by bin, without ballots: every lane
+//       ORs its lane bit into the 64-bit LDS mask of each bin it touches (order-free atomics),
+//       a contribution's rank inside its bin is the popcount of that mask below the lane, bin
+//       offsets are a 128-entry scan of the mask popcounts; the values land bin-major in LDS,
+//       in sample order inside each bin;
+//   3   lane L owns bins 2L and 2L+1 and adds their segments in order to its two fp32
+//       accumulators -- every bin sees exactly the reference's sequence of additions.
 #include "internal.hpp"
 #include "devmath.hpp"
 
 namespace {
 
-constexpr int REC_CAP = 256;         // records (surviving samples) buffered per flush
-constexpr int LIST_CAP = 128;        // entries per spatial-cell list per flush
 constexpr int QCAP = 128;            // survivor queue (power of two, >= 2 x 64)
 
 struct DescLds {
-	float w[4][REC_CAP];             // w_x of (dy,dx) = (0,0),(0,1),(1,0),(1,1)   (sift.cc:59-61)
-	float hb[REC_CAP];               // hbind
-	float omh[REC_CAP];              // 1 - hbind
-	// entry = record | u << 9 | h0 << 11 ; row pitch LIST_CAP + 8: the 16 cells' 16-byte reads hit disjoint banks
-	__attribute__((aligned(16))) unsigned short list[16][LIST_CAP + 8];
-	int len[16];
+	unsigned long long mask[128];    // per bin: bit l = lane l's sample of the current batch contributes
+	float sorted[512];               // the batch's contributions, bin-major, sample order inside a bin
+	unsigned short off[128];         // first slot of every bin in sorted[]
 	float hist[128];
 	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates
 	float q_xr[QCAP], q_yr[QCAP];
@@ -44,7 +42,8 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 	const float pi2 = (float)(2 * 3.14159265358979323846);
 	const float nbin_per_rad = 8 / pi2;
-	const int cell = lane >> 2, hj = lane & 3;
+	S.mask[2 * lane] = 0ULL; S.mask[2 * lane + 1] = 0ULL;
+	__syncthreads();
 
 	long long total = img_offset[p.n];                 // device-side count (k_image_offsets)
 	total = total < cap ? total : cap;                 // speculative capacity: the host re-runs on overflow
@@ -65,64 +64,16 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		const float cosort = opdev::cosf_glibc(ort), sinort = opdev::sinf_glibc(ort);
 		const int side = 2 * radius + 1, nsamp = side * side;
 		const float fr2 = (float)radius * (float)radius;
-		float acc0 = 0.f, acc1 = 0.f;     // bins (cell, hj) and (cell, hj + 4)
-		int nrec = 0;                     // records buffered (wave-uniform)
-		int len[16];                      // list lengths (wave-uniform)
-#pragma unroll
-		for (int c = 0; c < 16; ++c) len[c] = 0;
-		int maxlen = 0;
+		float acc0 = 0.f, acc1 = 0.f;     // bins 2 * lane and 2 * lane + 1
 		int qhead = 0, qn = 0;            // survivor queue state (wave-uniform)
 
-		auto flush = [&]() {
-			// phase 2: ordered accumulation from the cell lists
-			if (lane < 16) {
-				int v = 0;
-#pragma unroll
-				for (int c = 0; c < 16; ++c) v = (lane == c) ? len[c] : v;
-				S.len[lane] = v;
-			}
-			__syncthreads();
-			const int mylen = S.len[cell];
-			const unsigned short* mylist = S.list[cell];
-			// 8 list entries per step: one 16-byte LDS read for the entries, then their 16 operand
-			// reads back to back, then the 8 ordered additions.  Entries past the end of this
-			// cell's list are stale data: they are masked to a +0.0f contribution (exact).
-			for (int t0 = 0; t0 < maxlen; t0 += 8) {
-				const uint4 pk = *(const uint4*)(mylist + t0);
-				const unsigned e2[4] = {pk.x, pk.y, pk.z, pk.w};
-				float wx[8], fac[8]; int dd[8], hh[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					const unsigned e = (e2[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-					const int ridx = e & (REC_CAP - 1), u = (e >> 9) & 3, h0 = (e >> 11) & 7;
-					const int d = (hj - h0) & 3;
-					wx[k] = S.w[u][ridx];
-					fac[k] = d ? S.hb[ridx] : S.omh[ridx];
-					dd[k] = (t0 + k < mylen) ? d : 3;          // 3: contributes +0.0f
-					hh[k] = ((h0 + d) >> 2) & 1;                // bin hbinf%8 / (hbinf+1)%8 in the upper half?
-				}
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					const float v = wx[k] * fac[k];             // sift.cc:63-64
-					const float c = dd[k] < 2 ? v : 0.f;        // + 0.0f is exact
-					acc0 += hh[k] ? 0.f : c;
-					acc1 += hh[k] ? c : 0.f;
-				}
-			}
-			__syncthreads();
-			nrec = 0; maxlen = 0;
-#pragma unroll
-			for (int c = 0; c < 16; ++c) len[c] = 0;
-		};
-
-		// phases 1b + 1c on one dense batch of queued survivors (window order preserved)
+		// phases 1b - 3 on one dense batch of queued survivors (window order preserved)
 		auto process_batch = [&](int n) {
-			// flush first if this batch could overflow a buffer
-			if (nrec + 64 > REC_CAP || maxlen + 64 > LIST_CAP) flush();
 			const bool ok = lane < n;
 			const int qi = (qhead + lane) & (QCAP - 1);
-			const int ridx = nrec + lane;
-			int yb = -9, xb = -9, h0 = 0;
+			int bin[8]; float val[8];
+#pragma unroll
+			for (int c = 0; c < 8; ++c) { bin[c] = -1; val[c] = 0.f; }
 			if (ok) {
 				const int gi = S.q_gi[qi];
 				const float x_rot = S.q_xr[qi], y_rot = S.q_yr[qi];
@@ -137,25 +88,48 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				if (now_ort < 0) now_ort += pi2;
 				if (now_ort > pi2) now_ort -= pi2;
 				const float hbin = now_ort * nbin_per_rad;
+				// trilinear_interpolate (sift.cc:48-67)
 				const float yf = floorf(ybin), xf = floorf(xbin), hf = floorf(hbin);
-				yb = (int)yf; xb = (int)xf; h0 = ((int)hf) & 7;     // hbinf % 8 (hbinf in 0..8)
+				const int yb = (int)yf, xb = (int)xf, h0 = (int)hf;
 				const float ybind = ybin - yf, xbind = xbin - xf, hbind = hbin - hf;
-				const float wy0 = weight * (1 - ybind), wy1 = weight * ybind;
-				S.w[0][ridx] = wy0 * (1 - xbind); S.w[1][ridx] = wy0 * xbind;
-				S.w[2][ridx] = wy1 * (1 - xbind); S.w[3][ridx] = wy1 * xbind;
-				S.hb[ridx] = hbind; S.omh[ridx] = 1 - hbind;
-			}
-			nrec += n;
-			// phase 1c: ordered per-cell lists
+				const float omh = 1 - hbind;
 #pragma unroll
-			for (int c = 0; c < 16; ++c) {
-				const int dy = (c >> 2) - yb, dx = (c & 3) - xb;
-				const bool touch = ok && (unsigned)dy < 2u && (unsigned)dx < 2u;
-				const unsigned long long m = __ballot(touch);
-				if (touch) S.list[c][len[c] + __popcll(m & lt_mask)] = (unsigned short)(ridx | ((dy * 2 + dx) << 9) | (h0 << 11));
-				len[c] += __popcll(m);
-				maxlen = len[c] > maxlen ? len[c] : maxlen;
+				for (int dy = 0; dy < 2; ++dy) {
+					const float w_y = weight * (dy ? ybind : 1 - ybind);
+#pragma unroll
+					for (int dx = 0; dx < 2; ++dx) {
+						const int cy = yb + dy, cx = xb + dx;
+						if ((unsigned)cy < 4u && (unsigned)cx < 4u) {        // between(., 0, DESC_HIST_WIDTH)
+							const float w_x = w_y * (dx ? xbind : 1 - xbind);
+							const int cellbase = (cy * 4 + cx) * 8, u = dy * 2 + dx;
+							bin[2 * u] = cellbase + (h0 & 7);          val[2 * u] = w_x * omh;       // hbinf % 8
+							bin[2 * u + 1] = cellbase + ((h0 + 1) & 7);  val[2 * u + 1] = w_x * hbind;  // (hbinf + 1) % 8
+						}
+					}
+				}
 			}
+			// phase 2: stable counting sort of the contributions by bin
+#pragma unroll
+			for (int c = 0; c < 8; ++c)
+				if (bin[c] >= 0) atomicOr(&S.mask[bin[c]], 1ULL << lane);
+			__syncthreads();
+			const unsigned long long m0 = S.mask[2 * lane], m1 = S.mask[2 * lane + 1];
+			const int c0 = __popcll(m0), c1 = __popcll(m1);
+			int incl = c0 + c1;                               // inclusive wave scan of the per-lane pair counts
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+			const int ex = incl - (c0 + c1);
+			S.off[2 * lane] = (unsigned short)ex; S.off[2 * lane + 1] = (unsigned short)(ex + c0);
+			__syncthreads();
+#pragma unroll
+			for (int c = 0; c < 8; ++c)
+				if (bin[c] >= 0) S.sorted[S.off[bin[c]] + __popcll(S.mask[bin[c]] & lt_mask)] = val[c];
+			__syncthreads();
+			// phase 3: ordered accumulation of this lane's two bins
+			for (int e = 0; e < c0; ++e) acc0 += S.sorted[ex + e];
+			for (int e = 0; e < c1; ++e) acc1 += S.sorted[ex + c0 + e];
+			S.mask[2 * lane] = 0ULL; S.mask[2 * lane + 1] = 0ULL;
+			__syncthreads();
 			qhead = (qhead + n) & (QCAP - 1); qn -= n;
 		};
 
@@ -193,11 +167,10 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			if (qn >= 64) { __syncthreads(); process_batch(64); }
 		}
 		if (qn > 0) { __syncthreads(); process_batch(qn); }
-		flush();
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
-		S.hist[cell * 8 + hj] = acc0;
-		S.hist[cell * 8 + hj + 4] = acc1;
+		S.hist[2 * lane] = acc0;
+		S.hist[2 * lane + 1] = acc1;
 		__syncthreads();
 		float sum = 0.f;
 		for (int i = 0; i < 128; ++i) sum += S.hist[i];
