@@ -236,18 +236,21 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 // Samples are evaluated 64 at a time, but each histogram bin is accumulated by ONE lane walking
 // the samples in the reference's (xx outer, yy inner) order, so the fp32 sums round identically.
 constexpr int ORI_BINS = 36;
-constexpr int ORI_CHUNK = 1024;            // samples staged in LDS per pass (order-preserving chunks)
 
 __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* refined, const int* refined_count,
 		int cap, float* dirs, int* ndirs) {
-	__shared__ float s_val[ORI_CHUNK];
-	__shared__ signed char s_bin[ORI_CHUNK];
+	__shared__ unsigned long long s_mask[ORI_BINS];   // per bin: bit l = lane l's sample of this round falls into it
+	__shared__ float s_sorted[64];                     // the round's values, bin-major, sample order inside a bin
+	__shared__ unsigned short s_off[64];
 	__shared__ float s_hist[ORI_BINS];
 	const int img = blockIdx.y;
 	const int count = refined_count[img];
 	const int lane = threadIdx.x;
+	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 	const float* base = p.ws + (long long)img * p.ws_stride;
 	const float halfipi = (float)(0.5f / 3.14159265358979323846);
+	if (lane < ORI_BINS) s_mask[lane] = 0ULL;
+	__syncthreads();
 	for (int k = blockIdx.x; k < count; k += gridDim.x) {
 		const KeyPoint kp = refined[(long long)img * cap + k];
 		const OctDesc od = p.oct[kp.oct];
@@ -260,13 +263,16 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 		const int side = 2 * rad, nsamp = side * side;
 		const float frad2 = (float)rad * (float)rad;
 		float h = 0.f;
-		for (int cb = 0; cb < nsamp; cb += ORI_CHUNK) {
-			const int cn = nsamp - cb < ORI_CHUNK ? nsamp - cb : ORI_CHUNK;
-			for (int i = lane; i < cn; i += 64) {
-				const int e = cb + i;
-				const int xx = e / side - rad, yy = e % side - rad;
+		// 64 samples per round in the reference's (xx outer, yy inner) order.  The round's values
+		// are sorted by bin with order-free LDS mask ORs and popcount ranks (stable: sample order is
+		// kept inside a bin), then lane b adds bin b's segment in order -- the fp32 sums round like
+		// the sequential  hist[bin] += ...  of orientation.cc:49-66.
+		int qx = lane / (side > 0 ? side : 1), qy = lane % (side > 0 ? side : 1);
+		for (int i0 = 0; i0 < nsamp; i0 += 64) {
+			int bin = -1; float val = 0.f;
+			if (i0 + lane < nsamp) {
+				const int xx = qx - rad, yy = qy - rad;
 				const int newx = kp.x + xx, newy = kp.y + yy;
-				int bin = -1; float val = 0.f;
 				if (newx >= 1 && newx <= od.w - 2 && newy >= 1 && newy <= od.h - 2) {
 					const float fxx = (float)xx, fyy = (float)yy;
 					const float r2 = fxx * fxx + fyy * fyy;
@@ -281,12 +287,23 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 						val = weight * opdev::hypotf_glibc(gdx, gdy);
 					}
 				}
-				s_bin[i] = (signed char)bin; s_val[i] = val;
 			}
+			qy += 64;
+			while (qy >= side) { qy -= side; ++qx; }
+			if (bin >= 0) atomicOr(&s_mask[bin], 1ULL << lane);
 			__syncthreads();
-			if (lane < ORI_BINS)
-				for (int i = 0; i < cn; ++i)
-					if (s_bin[i] == lane) h += s_val[i];
+			const unsigned long long m = lane < ORI_BINS ? s_mask[lane] : 0ULL;
+			const int c = __popcll(m);
+			int incl = c;                                 // inclusive wave scan of the bin counts
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+			const int ex = incl - c;
+			s_off[lane] = (unsigned short)ex;
+			__syncthreads();
+			if (bin >= 0) s_sorted[s_off[bin] + __popcll(s_mask[bin] & lt_mask)] = val;
+			__syncthreads();
+			for (int e = 0; e < c; ++e) h += s_sorted[ex + e];
+			if (lane < ORI_BINS) s_mask[lane] = 0ULL;
 			__syncthreads();
 		}
 		if (lane < ORI_BINS) s_hist[lane] = h;
