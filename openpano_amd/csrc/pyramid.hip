@@ -172,6 +172,14 @@ __device__ __forceinline__ void packed_taps(const float (&win)[N + 2 * C], const
 	for (int j = 0; j < N / 2; ++j) { out[2 * j] = acc[j].x; out[2 * j + 1] = acc[j].y; }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's
+// outstanding GLOBAL memory operations (s_waitcnt vmcnt(0)); the scale-space kernel streams its
+// results to HBM and never reads them back, so waiting for those stores at each of its 19
+// barriers only adds their write latency to every sigma step.
+__device__ __forceinline__ void lds_barrier() {
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // register-blocked passes for kernel half-width C (taps = 2C+1)
 template <int C, int RV>
 __device__ __forceinline__ void vpass_blocked(const float* __restrict__ In, float* __restrict__ VT,
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 	else if (tid < 2 * GC) hoff = (GR - 1) * PG + (tid - GC);
 	else if (tid < 2 * GC + TH) hoff = (1 + tid - 2 * GC) * PG;
 	else if (tid < NHALO) hoff = (1 + tid - 2 * GC - TH) * PG + GC - 1;
-	__syncthreads();
+	lds_barrier();
 
 	float prev[NPX], dprev[NPX], prev_h = 0.f;
 #pragma unroll
@@ -359,11 +367,11 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 		if (halo == 6 && C == 3) vpass_blocked<3, RV>(In, VT, kern, NC, pin, halo, tid);
 		else if (halo == 6 && C == 6) vpass_blocked<6, RV>(In, VT, kern, NC, pin, halo, tid);
 		else vpass_generic(In, VT, kern, C, NC, pin, halo, tid);
-		__syncthreads();
+		lds_barrier();
 		if (halo == 6 && C == 3) hpass_blocked<3, RH>(VT, G, kern, NC, halo, tid);
 		else if (halo == 6 && C == 6) hpass_blocked<6, RH>(VT, G, kern, NC, halo, tid);
 		else hpass_generic(VT, G, kern, C, halo, tid);
-		__syncthreads();
+		lds_barrier();
 
 		const int d = s - 1;                                 // DoG layer produced by this sigma
 		float* Dcur = Dr + (d % 3) * (GR * PG);
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 			Dcur[hoff] = fabsf(prev_h - cur);
 			prev_h = cur;
 		}
-		__syncthreads();
+		lds_barrier();
 		if (d >= 2 && xin) {                                 // layers d-2, d-1, d in LDS: scan d-1 (extrema.cc:42)
 			const int j = d - 1;
 			const float* D0 = Dr + (j % 3) * (GR * PG);
