@@ -1,11 +1,15 @@
-// pyramid.hip -- source image -> working image -> octave bases -> fused scale-space kernel.
+// pyramid.hip -- source image -> grey octave bases -> fused scale-space + extrema-scan kernel.
 //
 // Replaces, for a whole batch of images per launch:
-//   resize<float>/resize_bilinear          lib/imgproc.cc:22-80,319-326
+//   resize<float>/resize_bilinear          lib/imgproc.cc:22-80,319-326 (working image and octaves)
+//   read_img's byte conversion             lib/imgio.cc:54-56,75-77     (OP_U8 sources)
 //   rgb2grey                               lib/imgproc.cc:237-249
 //   GaussianBlur::blur<float> (6 sigmas)   feature/gaussian.hh:30-91, feature/dog.cc:53-57
-//   GaussianPyramid::cal_mag_ort           feature/dog.cc:60-94 (+ fast_atan :22-37)
 //   DOGSpace::diff                         feature/dog.cc:116-129
+//   ExtremaDetector::get_local_raw_extrema feature/extrema.cc:170-216
+// GaussianPyramid::cal_mag_ort (feature/dog.cc:60-94) is not materialised: the orientation and
+// descriptor kernels evaluate it on the Gaussian planes for the samples they read; the debug
+// dump computes the planes with k_magort_plane.
 //
 // Numerics: fp32 multiply and add kept separate and in the reference's order (this TU is built
 // with -ffp-contract=off), so every plane is bit-identical to the CPU path.
@@ -121,12 +125,7 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 	}
 }
 
-// ---- K3: fused scale space -----------------------------------------------------------
-// One 256-thread workgroup owns a TW x TH tile of one octave and walks the 6 sigmas.  Per
-// sigma: separable blur of the *unblurred* grey tile (column pass, then row pass, replicate
-// borders -- feature/gaussian.hh:43-89) staged through LDS with register-blocked sliding
-// windows, then |DoG|, gradient magnitude and orientation straight to HBM.  The Gaussian planes
-// themselves only ever exist in LDS (two ping-pong buffers).
+// ---- K3: fused scale space + extrema scan: tile geometry (kernel and its description below) ----
 constexpr int TW = OP_PYR_TW, TH = OP_PYR_TH;
 constexpr int GR = TH + 2, GC = TW + 2;       // blurred region incl. the 1-px gradient halo
 constexpr int PG = TH == 16 ? 75 : GC + 1;    // pitch of G / DoG buffers: with RH = 6 the row pass's (row, strip) lanes hit 32 distinct banks
