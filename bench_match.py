@@ -38,6 +38,13 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
     flops = sum(2.0 * 128 * all_counts[i] * all_counts[j] for i, j in mine)
     m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up (and the match count)
     nmatch = sum(len(x) for x in m)
+    gather_results_ms = None
+    if dist is not None:                                             # results to every rank (rank 0 runs the host stages)
+        from openpano_amd.distributed import gather_match_results
+        barrier(); t0 = time.perf_counter()
+        allm = gather_match_results(mine, m, dev)
+        barrier(); gather_results_ms = (time.perf_counter() - t0) * 1e3
+        assert len(allm) == len(pairs)
     ctx.set_profiling(True); ctx.profile_reset()
     steps = max(1, min(args.steps, 10))
     barrier()
@@ -61,7 +68,7 @@ def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, 
     res = {
         "image_pairs_per_s": npairs * steps / tmax, "matches_per_s": nm * steps / tmax,
         "image_pairs": int(npairs), "matches": int(nm), "steps": steps, "ms_per_step": tmax / steps * 1e3,
-        "descriptor_allgather_ms": gather_ms, "stage_ms": {k: round(v, 4) for k, v in prof.items()},
+        "descriptor_allgather_ms": gather_ms, "match_results_gather_ms": gather_results_ms, "stage_ms": {k: round(v, 4) for k, v in prof.items()},
         "roofline": None,
     }
     if mfma_ms:

@@ -61,3 +61,34 @@ def partition_pairs(pairs, rank: int, world: int, counts=None):
         if r == rank:
             mine.append(pairs[k])
     return sorted(mine)
+
+
+def gather_match_results(pairs, match_lists, device, group=None):
+    """Step 3 of SURVEY 8(e): every rank matched its share of the pair list; the index pairs (a few
+    KB per image pair) are collected so that rank 0 -- which runs the host-only camera estimation
+    and the blend -- holds the whole job.  pairs: this rank's (i, j) list; match_lists: one (M, 2)
+    int32 array per pair.  Returns {(i, j): (M, 2) array} of ALL ranks (identical on every rank: the
+    exchange is an all-gather, cheap at this size and free of a root bottleneck over xGMI)."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    # header: (i, j, count) per pair, then the flat index pairs
+    hdr = np.array([[i, j, len(m)] for (i, j), m in zip(pairs, match_lists)], np.int64).reshape(-1, 3)
+    flat = np.concatenate([np.asarray(m, np.int64).reshape(-1, 2) for m in match_lists] + [np.zeros((0, 2), np.int64)])
+    sizes = torch.tensor([hdr.shape[0], flat.shape[0]], dtype=torch.int64, device=device)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    mh = max(1, max(int(s[0]) for s in all_sizes)); mf = max(1, max(int(s[1]) for s in all_sizes))
+    buf = torch.zeros((mh * 3 + mf * 2,), dtype=torch.int64, device=device)
+    buf[: hdr.size] = torch.from_numpy(hdr.reshape(-1)).to(device)
+    buf[mh * 3: mh * 3 + flat.size] = torch.from_numpy(flat.reshape(-1)).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    res = {}
+    for o, s in zip(out, all_sizes):
+        o = o.cpu().numpy()
+        h = o[: int(s[0]) * 3].reshape(-1, 3); f = o[mh * 3: mh * 3 + int(s[1]) * 2].reshape(-1, 2)
+        at = 0
+        for i, j, c in h:
+            res[(int(i), int(j))] = f[at: at + int(c)].astype(np.int32)
+            at += int(c)
+    return res
