@@ -673,8 +673,7 @@ int op_canvas_crop(op_ctx* ctx, const op_canvas* c, op_canvas** out, int* x0, in
 	HIPCHK(pool_alloc((void**)&d_height, sizeof(int) * (size_t)h * w)); fr.v.push_back(d_height);
 	HIPCHK(pool_alloc((void**)&d_best, sizeof(int4) * h)); fr.v.push_back(d_best);
 	HIPCHK(pool_alloc((void**)&d_rect, sizeof(int) * 4)); fr.v.push_back(d_rect);
-	static bool attr_set = false;
-	if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_crop_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr_set = true; }
+	HIPCHK(hipFuncSetAttribute((const void*)k_crop_lines, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));   // idempotent
 	int rect[4];
 	{ ProfScope ps(ctx, "crop");
 	  hipLaunchKernelGGL(k_crop_heights, dim3((w + 255) / 256), dim3(256), 0, st, c->data, h, w, d_height);

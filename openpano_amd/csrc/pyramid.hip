@@ -475,13 +475,11 @@ hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float
 }
 
 hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
-	static bool attr_set = false;
 	size_t lds = pyramid_lds_bytes(p.halo);
-	if (!attr_set) {
+	{	// per-function attribute; idempotent, so concurrent first calls from several host threads are harmless
 		hipError_t e = hipFuncSetAttribute((const void*)k_pyramid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pyramid<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e != hipSuccess) return e;
-		attr_set = true;
 	}
 	dim3 grid(p.total_tiles, p.n);
 	if (p.halo == 6) hipLaunchKernelGGL(k_pyramid<6>, grid, dim3(256), lds, st, p, raw, raw_count, cap);

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 size_t pyramid_lds_bytes(int halo);
 
@@ -41,9 +42,13 @@ struct Workspace {
 	}
 };
 
-static std::map<op_ctx*, Workspace*> g_ws;   // contexts are few and long-lived
+// contexts are few and long-lived; the table is shared by the host threads that own them (the
+// reference calls detect_feature concurrently from OpenMP threads, stitcherbase.cc:14)
+static std::map<op_ctx*, Workspace*> g_ws;
+static std::mutex g_ws_mu;
 
 static Workspace* ctx_workspace(op_ctx* c) {
+	std::lock_guard<std::mutex> lk(g_ws_mu);
 	auto it = g_ws.find(c);
 	if (it != g_ws.end()) return it->second;
 	Workspace* w = new Workspace;
@@ -51,9 +56,14 @@ static Workspace* ctx_workspace(op_ctx* c) {
 	return w;
 }
 void op_ctx_release_workspace(op_ctx* c) {
-	auto it = g_ws.find(c);
-	if (it == g_ws.end()) return;
-	it->second->release(); delete it->second; g_ws.erase(it);
+	Workspace* w = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_ws_mu);
+		auto it = g_ws.find(c);
+		if (it == g_ws.end()) return;
+		w = it->second; g_ws.erase(it);
+	}
+	w->release(); delete w;
 }
 
 struct op_features {

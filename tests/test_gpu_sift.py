@@ -196,3 +196,37 @@ def test_config5_sized_image(ctx, oracle, cfg):
         d, c = f.get(k)
         assert np.array_equal(d, od) and np.array_equal(c, oc), k
     f.free()
+
+
+def test_concurrent_contexts(oracle, cfg):
+    """The reference calls detect_feature concurrently from OpenMP threads (stitcherbase.cc:14);
+    the C-ABI is thread-compatible: one op_ctx per host thread, calls overlap (ctypes drops the GIL)."""
+    import threading
+    from openpano_amd import hip
+    world = synth.make_world(71, 330, 900, work_scale=1600.0 / (240 + 320), density=900.0)
+    views = [synth.cut_view(world, 20 + 5 * k, 20 + 60 * k, 240, 320, 50 + k) for k in range(8)]
+    want = [oracle.detect_feature(v) for v in views]
+    results = [None] * 8
+    errors = []
+
+    def worker(t):
+        try:
+            c = hip.Context(0)
+            for rep in range(3):
+                for k in range(t, 8, 4):
+                    f = hip.sift_batch(c, cfg, [views[k]])
+                    results[k] = f.get(0); f.free()
+            m = hip.match_pairs(c, cfg, hip.Features.from_host(c, [want[t][0], want[t + 4][0]]), [(0, 1)])[0]
+            assert np.array_equal(m, oracle.match_exact(want[t][0], want[t + 4][0]))
+            c.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(8):
+        assert np.array_equal(results[k][0], want[k][0]) and np.array_equal(results[k][1], want[k][1]), k
