@@ -1,0 +1,50 @@
+"""Non-default SIFT configurations (config.cfg is user-editable): other Gaussian windows (halo 4 and
+8: the generic, non-specialised scale-space kernel), scale / octave counts, working size, thresholds.
+CPU: the C oracle against the reference compiled in place; GPU: the HIP path against the oracle."""
+import numpy as np
+import pytest
+
+from openpano_amd import synth
+from openpano_amd.config import PanoConfig
+
+VARIANTS = {
+    "window4_3oct_6scales": dict(GAUSS_WINDOW_FACTOR=4, NUM_OCTAVE=3, NUM_SCALE=6, SIFT_WORKING_SIZE=600),
+    "window8_8scales_sf1.3": dict(GAUSS_WINDOW_FACTOR=8, NUM_SCALE=8, SCALE_FACTOR=1.3, GAUSS_SIGMA=1.2),
+    "thresholds": dict(CONTRAST_THRES=2e-2, PRE_COLOR_THRES=3e-2, EDGE_RATIO=10, JUDGE_EXTREMA_DIFF_THRES=1e-3,
+                       ORI_RADIUS=3.5, ORI_HIST_SMOOTH_COUNT=1, DESC_HIST_SCALE_FACTOR=2, CALC_OFFSET_DEPTH=3),
+}
+
+
+def _view():
+    world = synth.make_world(91, 300, 420, work_scale=1600.0 / (240 + 320), density=700.0)
+    return synth.cut_view(world, 20, 30, 240, 320, 9)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_oracle_equals_reference_under_config(ref, name):
+    from checkers import Oracle, sort_features
+    cfg = PanoConfig(**VARIANTS[name])
+    ref.set_config(**{k: v for k, v in cfg.raw_items()})
+    try:
+        img = _view()
+        rd, rc = sort_features(*ref.detect_feature(img))
+        od, oc = sort_features(*Oracle(cfg).detect_feature(img))
+    finally:
+        ref.set_config(**{k: v for k, v in PanoConfig().raw_items()})
+    assert len(rd) > 30 and np.array_equal(rd, od) and np.array_equal(rc, oc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_hip_equals_oracle_under_config(name):
+    from checkers import Oracle
+    from openpano_amd import hip
+    cfg = PanoConfig(**VARIANTS[name])
+    img = _view()
+    od, oc = Oracle(cfg).detect_feature(img)
+    ctx = hip.Context(0)
+    f = hip.sift_batch(ctx, cfg, [img, img])
+    for k in range(2):
+        d, c = f.get(k)
+        assert len(d) > 30 and np.array_equal(d, od) and np.array_equal(c, oc), (name, k)
+    f.free(); ctx.close()
