@@ -102,6 +102,12 @@ struct SiftPlan {
 	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
 	int kcenter[OP_MAX_SCALE];
 	int halo;                   // max kcenter
+	// Row-streaming scale-space kernel (k_pyramid_rows): available when the bank is the shipped one
+	// (7 scales, half-widths 3,3,3,6,6,6).  kpair[pl][d] = taps at distance d from the centre of the
+	// two sigmas (2 pl + 1, 2 pl + 2) that share one packed accumulator; a shorter kernel is
+	// zero-extended (adding +-0 leaves an fp32 sum unchanged, so the padding is exact).
+	int rows_ok;
+	float kpair[3][7][2];
 	// thresholds
 	float pre_color_thres, judge_thres, contrast_thres, edge_ratio, offset_thres;
 	int calc_offset_depth;

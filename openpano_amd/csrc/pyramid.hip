@@ -423,6 +423,264 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 	}
 }
 
+// ---- K3r: the same stage as K3, row-streaming form for the shipped Gaussian bank ---------------
+// A 256-thread workgroup owns a band of RW_OWN columns x SEG rows of one octave and walks down the
+// rows two at a time; nothing but two rows of column-pass results and four rows of DoG live in LDS.
+//   column pass: thread = column.  It keeps the 14 grey rows around the current row pair in
+//     registers (a sliding window fed by one coalesced load per row) and accumulates all six sigmas
+//     of both rows from it.  Two sigmas share one packed accumulator (v_pk_mul_f32 / v_pk_add_f32
+//     with the window element broadcast by op_sel and the two taps in an SGPR pair), so every
+//     multiply and every add of the reference's  tmp += line[i+k] * kernel[k]  (gaussian.hh:63-64)
+//     is one half of a packed instruction, in the reference's order; no LDS reads, no shifted copies.
+//   row pass: thread = two adjacent columns of one of the two rows; the (sigma a, sigma b) pairs
+//     written by the column pass are read back as 64-bit LDS words and used as packed operands as
+//     they are.  All six Gaussian values of a pixel end up in ONE thread: |DoG| (dog.cc:126) is
+//     register arithmetic, the ten planes leave as 8-byte stores on coalesced rows.
+//   scan: |DoG| rows go through a 4-row LDS ring.  Pixels passing the PRE_COLOR_THRES gate
+//     (extrema.cc:179) are compacted into an LDS queue and the 26-neighbour test (extrema.cc:181-207)
+//     runs one queue entry per thread, instead of every wave paying for its rarest lane.
+// Replicate borders (gaussian.hh:43-57,70-84) come from clamping the grey loads, as in K3.
+constexpr int RW_OWN = 240;           // columns owned by a band
+constexpr int RW_H = RW_OWN + 4;      // row-pass columns: x0 - 2 .. x0 + 241 (one ring column each side is used)
+constexpr int RW_QCAP = 1024;         // scan queue entries per row pair (overflow is handled in place)
+
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 w, f32x2 k) {      // (w.x * k.x, w.x * k.y)
+	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "s"(k)); return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 w, f32x2 k) {      // (w.y * k.x, w.y * k.y)
+	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "s"(k)); return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 w, f32x2 k) {         // (w.x * k.x, w.y * k.y)
+	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(w), "s"(k)); return r;
+}
+struct __attribute__((packed, aligned(4))) F2U { float a, b; };      // 8-byte store at a 4-byte aligned address
+
+// 26-neighbour test on the DoG ring (extrema.cc:181-207): slot = ring row of the centre
+__device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int slot, int L, int hc, float judge) {
+	const float center = sD[slot][L][hc];
+	const float cmp1 = center - judge, cmp2 = center + judge;
+	bool mx = true, mn = true;
+#pragma unroll
+	for (int di = -1; di <= 1; ++di) {
+		const int sl = (slot + di) & 3;
+#pragma unroll
+		for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+			for (int dj = -1; dj <= 1; ++dj) {
+				if (di == 0 && dl == 0 && dj == 0) continue;
+				const float v = sD[sl][L + dl][hc + dj];
+				if (v >= cmp1) mx = false;
+				if (v <= cmp2) mn = false;
+			}
+	}
+	return mx || mn;
+}
+
+template <int SEG>
+__global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int items, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
+	__shared__ f32x2 sV[3][2][256];          // column-pass results [sigma pair][row of the pair][column]
+	__shared__ float sGrey[2][256];
+	__shared__ float sD[4][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
+	__shared__ unsigned short sQ[RW_QCAP];
+	__shared__ int sQn[2];
+	const int tid = threadIdx.x;
+	// work item: consecutive items (neighbouring bands / segments, sharing halo rows) go to one XCD's L2
+	const unsigned lin = blockIdx.x, per = gridDim.x >> 3;
+	const unsigned swz = lin < per * 8 ? (lin & 7) * per + (lin >> 3) : lin;
+	const int img = (int)(swz / (unsigned)items);
+	int item = (int)(swz % (unsigned)items);
+	int o = 0, nb;
+	for (;;) {
+		nb = (p.oct[o].w + RW_OWN - 1) / RW_OWN;
+		const int cnt = nb * ((p.oct[o].h + SEG - 1) / SEG);
+		if (item < cnt || o + 1 == p.noct) break;
+		item -= cnt; ++o;
+	}
+	const OctDesc od = p.oct[o];
+	const int x0 = (item % nb) * RW_OWN, y0 = (item / nb) * SEG;
+	const int rows_own = od.h - y0 < SEG ? od.h - y0 : SEG;
+	const int nsteps = (rows_own + 3) >> 1;                       // row pairs (y0-1, y0), ... covering y0-1 .. y0+rows_own
+	float* ws = p.ws + (long long)img * p.ws_stride;
+	const float* grey = ws + plane_off_grey(od);
+
+	f32x2 KP0[4], KP1[7], KP2[7];                                // uniform: SGPR pairs
+#pragma unroll
+	for (int d = 0; d < 7; ++d) {
+		if (d < 4) KP0[d] = f32x2{p.kpair[0][d][0], p.kpair[0][d][1]};
+		KP1[d] = f32x2{p.kpair[1][d][0], p.kpair[1][d][1]};
+		KP2[d] = f32x2{p.kpair[2][d][0], p.kpair[2][d][1]};
+	}
+
+	// column-pass role: column x0 - 8 + tid, clamped
+	int xc = x0 - 8 + tid; xc = xc < 0 ? 0 : (xc > od.w - 1 ? od.w - 1 : xc);
+	const float* gcol = grey + xc;
+	auto grow = [&](int y) -> float { y = y < 0 ? 0 : (y > od.h - 1 ? od.h - 1 : y); return gcol[(unsigned)y * (unsigned)od.w]; };
+	f32x2 win[7];                                                 // grey rows r-6 .. r+7 of the current pair (r, r+1)
+#pragma unroll
+	for (int i = 0; i < 7; ++i) win[i] = f32x2{grow(y0 - 7 + 2 * i), grow(y0 - 6 + 2 * i)};
+
+	// row-pass role: row rr of the pair, columns h, h+1 (x = x0 - 2 + h)
+	const int rr = tid >> 7, j = tid & 127, h = 2 * j;
+	const bool hact = j < RW_H / 2;
+	const int x = x0 - 2 + h;
+	const bool own = j >= 1 && j <= RW_OWN / 2;                   // both columns owned by this band
+	const bool st0 = own && x < od.w, st1 = own && x + 1 < od.w;
+	const bool sc0 = st0 && x >= 1 && x <= od.w - 2, sc1 = st1 && x + 1 <= od.w - 2;   // extrema.cc:212
+	float dprev[2][4];                                            // this thread's |DoG| layers 1..4 of the previous pair
+#pragma unroll
+	for (int e = 0; e < 2; ++e)
+#pragma unroll
+		for (int l = 0; l < 4; ++l) dprev[e][l] = 0.f;
+	if (tid < 2) sQn[tid] = 0;
+
+	for (int t = 0; t < nsteps; ++t) {
+		const int r = y0 - 1 + 2 * t;
+		const f32x2 nxt = f32x2{grow(r + 8), grow(r + 9)};        // the next pair's two new rows, in flight during this one
+		{	// ---- column pass: rows r (window elements 0..12) and r+1 (1..13)
+			f32x2 a0[3], a1[3];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) { a0[pl] = f32x2{0.f, 0.f}; a1[pl] = f32x2{0.f, 0.f}; }
+#define OP_WMUL(i, kp) (((i) & 1) ? pk_mul_hi(win[(i) >> 1], kp) : pk_mul_lo(win[(i) >> 1], kp))
+#pragma unroll
+			for (int k = 0; k < 13; ++k) {
+				const int d = k < 6 ? 6 - k : k - 6;
+				a0[1] = a0[1] + OP_WMUL(k, KP1[d]); a1[1] = a1[1] + OP_WMUL(k + 1, KP1[d]);
+				a0[2] = a0[2] + OP_WMUL(k, KP2[d]); a1[2] = a1[2] + OP_WMUL(k + 1, KP2[d]);
+				if (k >= 3 && k <= 9) {
+					const int d0 = k < 6 ? 6 - k : k - 6;       // distance from the centre: 3..0..3
+					a0[0] = a0[0] + OP_WMUL(k, KP0[d0]); a1[0] = a1[0] + OP_WMUL(k + 1, KP0[d0]);
+				}
+			}
+#undef OP_WMUL
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) { sV[pl][0][tid] = a0[pl]; sV[pl][1][tid] = a1[pl]; }
+			sGrey[0][tid] = win[3].x; sGrey[1][tid] = win[3].y;
+		}
+		lds_barrier();
+
+		// ---- row pass + DoG for (row r + rr; columns h, h+1)
+		float dcur[2][6];
+		const int y = r + rr;
+		if (hact) {
+			f32x2 gA[3], gB[3];
+			{
+				f32x2 w[8];
+#pragma unroll
+				for (int i = 0; i < 8; ++i) w[i] = sV[0][rr][h + 3 + i];
+				f32x2 a = f32x2{0.f, 0.f}, b = f32x2{0.f, 0.f};
+#pragma unroll
+				for (int k = 0; k < 7; ++k) {
+					const int d = k < 3 ? 3 - k : k - 3;
+					a = a + pk_mul(w[k], KP0[d]); b = b + pk_mul(w[k + 1], KP0[d]);
+				}
+				gA[0] = a; gB[0] = b;
+			}
+#pragma unroll
+			for (int pl = 1; pl < 3; ++pl) {
+				f32x2 w[14];
+#pragma unroll
+				for (int i = 0; i < 14; ++i) w[i] = sV[pl][rr][h + i];
+				f32x2 a = f32x2{0.f, 0.f}, b = f32x2{0.f, 0.f};
+#pragma unroll
+				for (int k = 0; k < 13; ++k) {
+					const int d = k < 6 ? 6 - k : k - 6;
+					const f32x2 kp = pl == 1 ? KP1[d] : KP2[d];
+					a = a + pk_mul(w[k], kp); b = b + pk_mul(w[k + 1], kp);
+				}
+				gA[pl] = a; gB[pl] = b;
+			}
+			const float g0A = sGrey[rr][h + 6], g0B = sGrey[rr][h + 7];
+			// Gaussian stack of the two pixels: G[0] = grey (dog.cc:53), G[1..6]
+			const float GA[7] = {g0A, gA[0].x, gA[0].y, gA[1].x, gA[1].y, gA[2].x, gA[2].y};
+			const float GB[7] = {g0B, gB[0].x, gB[0].y, gB[1].x, gB[1].y, gB[2].x, gB[2].y};
+#pragma unroll
+			for (int l = 0; l < 6; ++l) { dcur[0][l] = fabsf(GA[l] - GA[l + 1]); dcur[1][l] = fabsf(GB[l] - GB[l + 1]); }   // dog.cc:126
+			const int slot = (2 * t + rr) & 3;
+#pragma unroll
+			for (int l = 0; l < 6; ++l) *(f32x2*)&sD[slot][l][h] = f32x2{dcur[0][l], dcur[1][l]};
+			if (st0 && y >= y0 && y < y0 + rows_own) {
+				const unsigned gi = (unsigned)y * (unsigned)od.w + (unsigned)x;
+				float* dog0 = ws + plane_off_dog(od, 0) + gi;
+				float* gau1 = ws + plane_off_gauss(od, 7, 1) + gi;
+				if (st1) {
+#pragma unroll
+					for (int l = 0; l < 6; ++l) *(F2U*)(dog0 + (long long)l * od.plane) = F2U{dcur[0][l], dcur[1][l]};
+#pragma unroll
+					for (int s = 1; s <= 4; ++s) *(F2U*)(gau1 + (long long)(s - 1) * od.plane) = F2U{GA[s], GB[s]};
+				} else {
+#pragma unroll
+					for (int l = 0; l < 6; ++l) dog0[(long long)l * od.plane] = dcur[0][l];
+#pragma unroll
+					for (int s = 1; s <= 4; ++s) gau1[(long long)(s - 1) * od.plane] = GA[s];
+				}
+			}
+		} else {
+#pragma unroll
+			for (int e = 0; e < 2; ++e)
+#pragma unroll
+				for (int l = 0; l < 6; ++l) dcur[e][l] = 0.f;
+		}
+
+		// ---- gate: rr == 0 scans its current row r (row r+1 is written by the other half in this
+		// pair), rr == 1 scans the row it produced in the previous pair (r-1)
+		const int ysc = rr == 0 ? y : y - 2;
+		unsigned mine = 0;                                        // candidates that did not fit the queue
+		{
+			unsigned mask = 0;
+			if (ysc >= y0 && ysc < y0 + rows_own && ysc >= 1 && ysc <= od.h - 2) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e)
+#pragma unroll
+					for (int l = 1; l <= 4; ++l) {
+						const float c = rr == 0 ? dcur[e][l] : dprev[e][l - 1];
+						if ((e == 0 ? sc0 : sc1) && !(c < p.pre_color_thres)) mask |= 1u << (e * 4 + l - 1);   // extrema.cc:179
+					}
+			}
+			if (mask) {
+				int base = atomicAdd(&sQn[t & 1], __popc(mask));
+				for (unsigned m = mask; m; m &= m - 1) {
+					const int b = __ffs(m) - 1;
+					if (base < RW_QCAP) sQ[base] = (unsigned short)((h + (b >> 2)) | (((b & 3) + 1) << 8) | (rr << 11));
+					else mine |= 1u << b;
+					++base;
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < 2; ++e)
+#pragma unroll
+			for (int l = 0; l < 4; ++l) dprev[e][l] = dcur[e][l + 1];
+		lds_barrier();
+
+		// ---- scan the queue: one entry per thread
+		if (tid == 0) sQn[(t + 1) & 1] = 0;
+		{
+			int n = sQn[t & 1]; n = n > RW_QCAP ? RW_QCAP : n;
+			for (int i = tid; i < n; i += 256) {
+				const unsigned code = sQ[i];
+				const int hc = code & 255, L = (code >> 8) & 7, qr = code >> 11;
+				const int slot = (2 * t + (qr ? -1 : 0)) & 3;
+				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) {
+					const int s = atomicAdd(&raw_count[img], 1);
+					if (s < cap) { int* q = raw + ((long long)img * cap + s) * 4; q[0] = x0 - 2 + hc; q[1] = r + (qr ? -1 : 0); q[2] = o; q[3] = L; }
+				}
+			}
+			for (unsigned m = mine; m; m &= m - 1) {
+				const int b = __ffs(m) - 1, hc = h + (b >> 2), L = (b & 3) + 1;
+				const int slot = (2 * t + (rr ? -1 : 0)) & 3;
+				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) {
+					const int s = atomicAdd(&raw_count[img], 1);
+					if (s < cap) { int* q = raw + ((long long)img * cap + s) * 4; q[0] = x0 - 2 + hc; q[1] = ysc; q[2] = o; q[3] = L; }
+				}
+			}
+		}
+		// slide the window by one row pair
+#pragma unroll
+		for (int i = 0; i < 6; ++i) win[i] = win[i + 1];
+		win[6] = nxt;
+	}
+}
+
 // debug / staged dump: GaussianPyramid::cal_mag_ort (feature/dog.cc:60-94) of one Gaussian plane
 __global__ void __launch_bounds__(256) k_magort_plane(SiftPlan p, int img, int o, int s, float* mag, float* ort) {
 	const OctDesc od = p.oct[o];
@@ -474,12 +732,25 @@ hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float
 	return hipGetLastError();
 }
 
+// OPENPANO_PYRAMID=tiles selects the tiled kernel (K3) also for the shipped bank (tests, A/B timing)
+static bool pyramid_force_tiles() {
+	static const bool v = [] { const char* e = getenv("OPENPANO_PYRAMID"); return e && std::string(e) == "tiles"; }();
+	return v;
+}
+
 hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
 	size_t lds = pyramid_lds_bytes(p.halo);
 	{	// per-function attribute; idempotent, so concurrent first calls from several host threads are harmless
 		hipError_t e = hipFuncSetAttribute((const void*)k_pyramid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pyramid<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e != hipSuccess) return e;
+	}
+	if (p.rows_ok && !pyramid_force_tiles()) {
+		constexpr int SEG = 32;
+		int items = 0;
+		for (int o = 0; o < p.noct; ++o) items += ((p.oct[o].w + RW_OWN - 1) / RW_OWN) * ((p.oct[o].h + SEG - 1) / SEG);
+		hipLaunchKernelGGL(k_pyramid_rows<SEG>, dim3((unsigned)items * (unsigned)p.n), dim3(256), 0, st, p, items, raw, raw_count, cap);
+		return hipGetLastError();
 	}
 	dim3 grid(p.total_tiles, p.n);
 	if (p.halo == 6) hipLaunchKernelGGL(k_pyramid<6>, grid, dim3(256), lds, st, p, raw, raw_count, cap);

@@ -150,6 +150,16 @@ int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
 	p.total_tiles = tile_begin;
 	p.ws_stride = (off + 63) & ~63LL;
 	if (build_gauss_bank(cfg, p) != 0) OP_FAIL(OP_ERR_UNSUPPORTED, "Gaussian kernel wider than 31 taps");
+	{
+		static const int shipped[6] = {3, 3, 3, 6, 6, 6};
+		p.rows_ok = p.nscale == 7;
+		for (int s = 1; s < 7 && p.rows_ok; ++s) if (p.kcenter[s] != shipped[s - 1]) p.rows_ok = 0;
+		if (p.rows_ok)
+			for (int pl = 0; pl < 3; ++pl) for (int d = 0; d < 7; ++d) for (int e = 0; e < 2; ++e) {
+				const int s = 2 * pl + 1 + e;
+				p.kpair[pl][d][e] = d <= p.kcenter[s] ? p.kern[s][OP_MAX_KCENTER + d] : 0.f;
+			}
+	}
 	if (pyramid_lds_bytes(p.halo) > 160 * 1024 - 256) OP_FAIL(OP_ERR_UNSUPPORTED, "Gaussian halo does not fit LDS");
 	p.pre_color_thres = cfg.PRE_COLOR_THRES; p.judge_thres = cfg.JUDGE_EXTREMA_DIFF_THRES;
 	p.contrast_thres = cfg.CONTRAST_THRES; p.edge_ratio = cfg.EDGE_RATIO; p.offset_thres = cfg.OFFSET_THRES;
