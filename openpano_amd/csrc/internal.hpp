@@ -81,7 +81,8 @@ void pool_trim();     // release every cached block back to the runtime
 // ---------------------------------------------------------------------------------------
 struct OctDesc {
 	int h, w;
-	int tiles_x, tiles_y, tile_begin;   // pyramid-kernel tiling
+	int tiles_x, tiles_y, tile_begin;   // pyramid-kernel tiling (k_pyramid)
+	int rw_nb, rw_nseg;                 // k_pyramid_rows: bands x row segments of this octave
 	long long off;                      // float offset of the octave block in the image workspace
 	long long plane;                    // h*w
 };
@@ -107,6 +108,7 @@ struct SiftPlan {
 	// two sigmas (2 pl + 1, 2 pl + 2) that share one packed accumulator; a shorter kernel is
 	// zero-extended (adding +-0 leaves an fp32 sum unchanged, so the padding is exact).
 	int rows_ok;
+	int rw_items;               // work items per image: sum over octaves of bands x segments
 	float kpair[3][7][2];
 	// thresholds
 	float pre_color_thres, judge_thres, contrast_thres, edge_ratio, offset_thres;
@@ -129,6 +131,8 @@ struct KeyPoint {
 	int pad;
 };
 
+#define OP_RW_OWN 240     // k_pyramid_rows: columns owned by a band
+#define OP_RW_SEG 16      // rows of a segment
 #define OP_PYR_TW 64
 #ifndef OP_PYR_TH
 #define OP_PYR_TH 16

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 }
 
 // ---- K3r: the same stage as K3, row-streaming form for the shipped Gaussian bank ---------------
-// A 256-thread workgroup owns a band of RW_OWN columns x SEG rows of one octave and walks down the
+// A 256-thread workgroup owns a band of RW_OWN columns x OP_RW_SEG rows of one octave and walks down the
 // rows two at a time; nothing but two rows of column-pass results and four rows of DoG live in LDS.
 //   column pass: thread = column.  It keeps the 14 grey rows around the current row pair in
 //     registers (a sliding window fed by one coalesced load per row) and accumulates all six sigmas
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 //     (extrema.cc:179) are compacted into an LDS queue and the 26-neighbour test (extrema.cc:181-207)
 //     runs one queue entry per thread, instead of every wave paying for its rarest lane.
 // Replicate borders (gaussian.hh:43-57,70-84) come from clamping the grey loads, as in K3.
-constexpr int RW_OWN = 240;           // columns owned by a band
+constexpr int RW_OWN = OP_RW_OWN;     // columns owned by a band
 constexpr int RW_H = RW_OWN + 4;      // row-pass columns: x0 - 2 .. x0 + 241 (one ring column each side is used)
 constexpr int RW_QCAP = 1024;         // scan queue entries per row pair (overflow is handled in place)
 
@@ -476,29 +476,28 @@ __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int sl
 	return mx || mn;
 }
 
-template <int SEG>
-__global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int items, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
+__global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
 	__shared__ f32x2 sV[3][2][256];          // column-pass results [sigma pair][row of the pair][column]
 	__shared__ float sGrey[2][256];
 	__shared__ float sD[4][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
 	__shared__ unsigned short sQ[RW_QCAP];
 	__shared__ int sQn[2];
 	const int tid = threadIdx.x;
-	// work item: consecutive items (neighbouring bands / segments, sharing halo rows) go to one XCD's L2
+	// work item; consecutive items (neighbouring bands share cache lines at their seams, neighbouring
+	// segments their halo rows) are handed to one XCD, i.e. one L2
 	const unsigned lin = blockIdx.x, per = gridDim.x >> 3;
 	const unsigned swz = lin < per * 8 ? (lin & 7) * per + (lin >> 3) : lin;
-	const int img = (int)(swz / (unsigned)items);
-	int item = (int)(swz % (unsigned)items);
-	int o = 0, nb;
+	const int img = (int)(swz / (unsigned)p.rw_items);
+	int item = (int)(swz % (unsigned)p.rw_items);
+	int o = 0;
 	for (;;) {
-		nb = (p.oct[o].w + RW_OWN - 1) / RW_OWN;
-		const int cnt = nb * ((p.oct[o].h + SEG - 1) / SEG);
+		const int cnt = p.oct[o].rw_nb * p.oct[o].rw_nseg;
 		if (item < cnt || o + 1 == p.noct) break;
 		item -= cnt; ++o;
 	}
 	const OctDesc od = p.oct[o];
-	const int x0 = (item % nb) * RW_OWN, y0 = (item / nb) * SEG;
-	const int rows_own = od.h - y0 < SEG ? od.h - y0 : SEG;
+	const int x0 = (item % od.rw_nb) * RW_OWN, y0 = (item / od.rw_nb) * OP_RW_SEG;
+	const int rows_own = od.h - y0 < OP_RW_SEG ? od.h - y0 : OP_RW_SEG;
 	const int nsteps = (rows_own + 3) >> 1;                       // row pairs (y0-1, y0), ... covering y0-1 .. y0+rows_own
 	float* ws = p.ws + (long long)img * p.ws_stride;
 	const float* grey = ws + plane_off_grey(od);
@@ -746,10 +745,8 @@ hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, 
 		if (e != hipSuccess) return e;
 	}
 	if (p.rows_ok && !pyramid_force_tiles()) {
-		constexpr int SEG = 32;
-		int items = 0;
-		for (int o = 0; o < p.noct; ++o) items += ((p.oct[o].w + RW_OWN - 1) / RW_OWN) * ((p.oct[o].h + SEG - 1) / SEG);
-		hipLaunchKernelGGL(k_pyramid_rows<SEG>, dim3((unsigned)items * (unsigned)p.n), dim3(256), 0, st, p, items, raw, raw_count, cap);
+		const unsigned blocks = (unsigned)p.n * (unsigned)p.rw_items;
+		hipLaunchKernelGGL(k_pyramid_rows, dim3(blocks), dim3(256), 0, st, p, raw, raw_count, cap);
 		return hipGetLastError();
 	}
 	dim3 grid(p.total_tiles, p.n);

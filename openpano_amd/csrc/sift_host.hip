@@ -154,6 +154,19 @@ int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
 		static const int shipped[6] = {3, 3, 3, 6, 6, 6};
 		p.rows_ok = p.nscale == 7;
 		for (int s = 1; s < 7 && p.rows_ok; ++s) if (p.kcenter[s] != shipped[s - 1]) p.rows_ok = 0;
+		if (p.rows_ok) {
+			// work items of k_pyramid_rows: bands of OP_RW_OWN columns x segments of OP_RW_SEG rows.
+			// Short segments win although each re-reads 14 halo rows and adds a row pair of column-pass
+			// work: measured on config 4, 16 rows 0.52 ms, 32 rows 0.57, 64 rows 0.59 (ramp-up and
+			// tail cost more than a workgroup lifetime, and the lifetime grows with the segment).
+			p.rw_items = 0;
+			for (int i = 0; i < p.noct; ++i) {
+				OctDesc& o = p.oct[i];
+				o.rw_nb = (o.w + OP_RW_OWN - 1) / OP_RW_OWN;
+				o.rw_nseg = (o.h + OP_RW_SEG - 1) / OP_RW_SEG;
+				p.rw_items += o.rw_nb * o.rw_nseg;
+			}
+		}
 		if (p.rows_ok)
 			for (int pl = 0; pl < 3; ++pl) for (int d = 0; d < 7; ++d) for (int e = 0; e < 2; ++e) {
 				const int s = 2 * pl + 1 + e;

@@ -18,7 +18,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 # kernel-name fragment -> bench.py stage label
-LABELS = {"k_grey_octaves": "resize + octave grey", "k_pyramid": "build pyramid",
+LABELS = {"k_grey_octaves": "resize + octave grey", "k_pyramid": "build pyramid", "k_pyramid_rows": "build pyramid",
           "k_extrema_scan": "extrema scan", "k_refine": "extrema refine", "k_sort_refined": "extrema refine",
           "k_orientation": "orientation", "k_descriptor": "sift descriptor",
           "k_match_top4": "matcher mfma top4", "k_match_decide": "matcher decide", "k_norms": "matcher norms",
