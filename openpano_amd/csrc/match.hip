@@ -5,8 +5,10 @@
 // FeatureMatcher::match (feature/matcher.cc:15-71) -- see SURVEY.md F2/F3 for why the
 // kd-forest's approximate, non-deterministic answers cannot be the parity target.
 //
-// ALL requested image pairs go through two launches of one fp32-MFMA sweep kernel
-// (v_mfma_f32_32x32x2_f32 dot-product tiles, running per-row top-4 by score = x.y - |y|^2/2):
+// ALL requested image pairs go through two launches of one MFMA sweep kernel (dot-product tiles
+// from three v_mfma_f32_32x32x16_bf16 per 16 elements on a two-term bf16 split of the descriptors
+// -- x = hi + lo, x.y ~ hi.hi + hi.lo + lo.hi, fp32 accumulation: 2^-16-accurate at 5x the rate of
+// the fp32 MFMA -- and a running per-row top-4 by score = x.y - |y|^2/2):
 // a forward sweep of every row of the smaller set, whose epilogue re-scores the ranked
 // candidates with the reference's exact squared L2 and applies the first ratio test, and a
 // reverse sweep over the survivors only, whose epilogue applies the second test.  MFMA results
@@ -31,6 +33,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // One MFMA sweep kernel serves both directions of FeatureMatcher::match:
 //   FWD  rows = every descriptor of the smaller set A, columns = B: exact 2-NN + the first ratio
@@ -53,6 +56,29 @@ __global__ void __launch_bounds__(256) k_norms(const float* desc, long long tota
 	for (int t = 0; t < 32; ++t) { f32x4 v = p[t]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 	norms[i] = s;
 	if (s == s) atomicMax(gmax_bits, __float_as_uint(s));     // a NaN descriptor must not poison the margin of every row
+}
+
+// Two-term bf16 split of every descriptor, row r -> [128 x hi][128 x lo] (512 B): hi = bf16(v)
+// (round to nearest even), lo = bf16(v - hi); v - hi is exact in fp32, so |v - hi - lo| <= 2^-18 |v|.
+// NaN stays NaN in both terms (such a row / column must simply never rank).
+__device__ __forceinline__ unsigned bf16_rn(float v) {
+	const unsigned u = __float_as_uint(v);
+	return v != v ? 0x7fc0u : (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ desc, long long total, uint4* __restrict__ split) {
+	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 8 consecutive elements
+	if (i >= total * 16) return;
+	const long long row = i >> 4; const int c = (int)(i & 15);
+	const f32x4* p = (const f32x4*)(desc + row * 128 + c * 8);
+	const f32x4 a = p[0], b = p[1];
+	const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	unsigned hi[8], lo[8];
+#pragma unroll
+	for (int e = 0; e < 8; ++e) { hi[e] = bf16_rn(v[e]); lo[e] = bf16_rn(v[e] - __uint_as_float(hi[e] << 16)); }
+	uint4 H, L;
+	H.x = hi[0] | (hi[1] << 16); H.y = hi[2] | (hi[3] << 16); H.z = hi[4] | (hi[5] << 16); H.w = hi[6] | (hi[7] << 16);
+	L.x = lo[0] | (lo[1] << 16); L.y = lo[2] | (lo[3] << 16); L.z = lo[4] | (lo[5] << 16); L.w = lo[6] | (lo[7] << 16);
+	split[row * 32 + c] = H; split[row * 32 + 16 + c] = L;
 }
 
 // running top-NK (descending score); the common case is the single rejecting compare.  NK = 4:
@@ -89,7 +115,7 @@ __device__ __forceinline__ float euclidean_sqr_exact(const float* __restrict__ x
 
 // device-side state of one op_match_pairs call
 struct MatchState {
-	const float* desc; const float* norms; const unsigned* gmax_bits;
+	const float* desc; const uint4* split; const float* norms; const unsigned* gmax_bits;
 	const PairDesc* pairs;
 	int* fb;            // per A row: forward best column b*, -1 rejected, -2 needs the exact full scan
 	float* fmn;         // per A row: exact min distance
@@ -122,8 +148,8 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 	}
 }
 
-// One workgroup = 128 rows of X (4 waves x 32 rows, X fragments resident in VGPRs) against all
-// of Y, streamed through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
+// One workgroup = 128 rows of X (4 waves x 32 rows, the split X fragments resident in VGPRs) against
+// all of Y, whose split rows stream through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
 // holding 16 scores of ONE X row (C/D layout: col = lane&31), which makes the running top-4 a
 // purely per-lane update; the two lane halves (k < 64 / k >= 64 of the row) are merged once at
 // the end.  MFMA scores (x.y - |y|^2/2 = const - d/2) only RANK columns.  The epilogue then
@@ -133,8 +159,9 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 // lower half walks t = 0..15, hands its four partial sums to the upper half, which walks
 // t = 16..31 -- candidates are software-pipelined through the two halves.  The candidate set is
 // provably complete: every column whose score is within E of the 2nd best is re-scored, where E
-// bounds twice the worst-case fp32 error of score vs. exact distance; if all 4 kept entries
-// fall inside the margin the row is queued for an exact full scan instead.
+// bounds twice the worst-case error of a score (dropped split terms 3 * 2^-18, 384 fp32
+// accumulations, the fp32 norm) plus the rounding of the reference's own fp32 distance; if all 4
+// kept entries fall inside the margin the row is queued for an exact full scan instead.
 template <bool REV>
 __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
 	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
@@ -158,12 +185,11 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 	const int a_row = REV ? S.surv[pd.res_off + rowc] : rowc;
 	const int x_idx = REV ? S.fb[pd.res_off + a_row] : a_row;
 	const float* X = (REV ? B : A) + (long long)x_idx * 128;
-	f32x4 xf[16];     // row elements [64h, 64h+64)
-	{
-		const f32x4* px = (const f32x4*)(X + 64 * h);
+	const uint4* XS = S.split + ((long long)(REV ? pd.b_off : pd.a_off) + x_idx) * 32;
+	const uint4* YS = S.split + (long long)(REV ? pd.a_off : pd.b_off) * 32;
+	uint4 xh[8], xl[8];   // MFMA B operands: block kb covers k = 16 kb + 8 h .. + 7 of row j
 #pragma unroll
-		for (int q = 0; q < 16; ++q) xf[q] = px[q];
-	}
+	for (int kb = 0; kb < 8; ++kb) { xh[kb] = XS[2 * kb + h]; xl[kb] = XS[16 + 2 * kb + h]; }
 	float ts[NK]; int ti[NK];
 #pragma unroll
 	for (int r = 0; r < NK; ++r) { ts[r] = -FLT_MAX; ti[r] = -1; }
@@ -171,16 +197,16 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 
 	// global -> registers and registers -> LDS are split so that the next tile's loads are in flight
 	// while the MFMAs of the current tile run; the LDS store happens after them
-	f32x4 stage[4]; float stage_ny = 0.f;
+	uint4 stage[4]; float stage_ny = 0.f;
 	auto fetch_tile = [&](int t) {
-		// 32 rows x 128 floats = 1024 float4, 4 per thread
+		// 32 split rows x 512 B = 1024 x 16 B, 4 per thread
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			const int e = tid + 256 * r;          // float4 index
+			const int e = tid + 256 * r;          // 16-byte index
 			const int yr = e >> 5, c4 = e & 31;
 			const int gy = t * 32 + yr;
-			f32x4 v = {0.f, 0.f, 0.f, 0.f};
-			if (gy < ky) v = *(const f32x4*)(Y + (long long)gy * 128 + c4 * 4);
+			uint4 v = {0u, 0u, 0u, 0u};
+			if (gy < ky) v = YS[(long long)gy * 32 + c4];
 			stage[r] = v;
 		}
 		if (tid < 32) {
@@ -192,7 +218,7 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const int e = tid + 256 * r;
-			*(f32x4*)(&s_y[buf][(e >> 5) * YP + (e & 31) * 4]) = stage[r];
+			*(uint4*)(&s_y[buf][(e >> 5) * YP + (e & 31) * 4]) = stage[r];
 		}
 		if (tid < 32) s_nyh[buf][tid] = stage_ny;
 	};
@@ -204,14 +230,14 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 		const int buf = t & 1;
 		if (t + 1 < ntiles) fetch_tile(t + 1);
 		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-		const float* yrow = &s_y[buf][j * YP + 64 * h];
+		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
 #pragma unroll
-		for (int q = 0; q < 16; ++q) {
-			const f32x4 av = *(const f32x4*)(yrow + 4 * q);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, xf[q].x, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, xf[q].y, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, xf[q].z, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, xf[q].w, acc, 0, 0, 0);
+		for (int kb = 0; kb < 8; ++kb) {
+			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
+			const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[kb]), bl = __builtin_bit_cast(bf16x8, xl[kb]);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
 #pragma unroll
@@ -237,7 +263,7 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 
 	// ---- candidate set (identical in both halves): merged top-NK entries within E of the 2nd best ----
 	const float gmax = __uint_as_float(*S.gmax_bits);
-	const float E = 3.2e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
+	const float E = 8e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
 	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];
 	const float thr = ms[1] - E;
 	const bool overflow = mi[NK - 1] >= 0 && ms[NK - 1] >= thr;     // even the NK-th entry is inside the margin
@@ -262,6 +288,12 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 	for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(ncmax, off); ncmax = o > ncmax ? o : ncmax; }
 
 	// ---- exact re-score, pipelined through the lane halves ----
+	f32x4 xf[16];     // fp32 row elements [64h, 64h+64)
+	{
+		const f32x4* px = (const f32x4*)(X + 64 * h);
+#pragma unroll
+		for (int q = 0; q < 16; ++q) xf[q] = px[q];
+	}
 	float mn = REV ? 0.f : FLT_MAX, next_min = FLT_MAX; int min_idx = -1;
 	if (REV) next_min = S.fnext[pd.res_off + a_row];
 	float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -381,7 +413,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
 	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
-	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr;
+	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr; uint4* d_split = nullptr;
 	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_mlist = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
 	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr;
 	// accepted matches come back as one packed list (count + triples); the first copy takes a
@@ -392,6 +424,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	if (!h_ml) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
 	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
+	MCHK(pool_alloc((void**)&d_split, 512 * (size_t)total));
 	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
 	MCHK(pool_alloc((void**)&d_fmn, sizeof(float) * nres));
 	MCHK(pool_alloc((void**)&d_fnext, sizeof(float) * nres));
@@ -413,10 +446,12 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		ProfScope ps(ctx, "matcher norms");
 		hipLaunchKernelGGL(k_norms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, fv.desc, total, d_norms, d_gmax);
 		MCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, fv.desc, total, d_split);
+		MCHK(hipGetLastError());
 	}
 	if (!work.empty()) {
 		MatchState S;
-		S.desc = fv.desc; S.norms = d_norms; S.gmax_bits = d_gmax; S.pairs = d_pds;
+		S.desc = fv.desc; S.split = d_split; S.norms = d_norms; S.gmax_bits = d_gmax; S.pairs = d_pds;
 		S.fb = d_fb; S.fmn = d_fmn; S.fnext = d_fnext; S.surv = d_surv; S.nsurv = d_nsurv; S.mlist = d_mlist;
 		S.slow_fwd = d_slow; S.slow_rev = d_slow + 1 + 2 * (size_t)slow_cap; S.slow_cap = slow_cap;
 		S.rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
@@ -468,7 +503,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		}
 	}
 done:
-	pool_free(d_norms); pool_free(d_gmax); pool_free(d_fmn); pool_free(d_fnext); pool_free(d_fb); pool_free(d_surv);
+	pool_free(d_norms); pool_free(d_split); pool_free(d_gmax); pool_free(d_fmn); pool_free(d_fnext); pool_free(d_fb); pool_free(d_surv);
 	pool_free(d_nsurv); pool_free(d_mlist); pool_free(d_slow); pool_free(d_work); pool_free(d_pds);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
