@@ -163,9 +163,9 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 // accumulations, the fp32 norm) plus the rounding of the reference's own fp32 distance; if all 4
 // kept entries fall inside the margin the row is queued for an exact full scan instead.
 template <bool REV>
-__global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
 	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
-	__shared__ float s_nyh[2][32];
+	__shared__ __attribute__((aligned(16))) float s_nyh[2][32];
 	__shared__ float s_ms[4][32][2][NK];
 	__shared__ int s_mi[4][32][2][NK];
 	const WorkItem wk = work[blockIdx.x];
@@ -231,6 +231,11 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 		if (t + 1 < ntiles) fetch_tile(t + 1);
 		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
+		// |y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h, fetched ahead of the MFMA
+		// chain (one LDS round trip instead of sixteen serialised ones in front of the top-4 updates)
+		f32x4 nyh[4];
+#pragma unroll
+		for (int g = 0; g < 4; ++g) nyh[g] = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
 			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
@@ -243,7 +248,7 @@ __global__ void __launch_bounds__(256) k_match_sweep(MatchState S, const WorkIte
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-			const float sc = acc[reg] - s_nyh[buf][i];
+			const float sc = acc[reg] - nyh[reg >> 2][reg & 3];
 			topk_insert(ts, ti, sc, t * 32 + i);
 		}
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
@@ -408,6 +413,17 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
 		if (pd.ka > 0 && pd.kb > 0)
 			for (int rb = 0; rb * 128 < pd.ka; ++rb) work.push_back({p, rb});
+	}
+	{	// Workgroups are handed to the 8 XCDs round-robin by index.  Re-order the list so that the row
+		// blocks of one pair (which stream the same Y set) run on ONE XCD at about the same time:
+		// Y then comes from HBM once and from that XCD's L2 for the other row blocks.
+		const size_t per = work.size() >> 3;
+		if (per > 0) {
+			std::vector<WorkItem> w2(work.size());
+			for (size_t lin = 0; lin < work.size(); ++lin)
+				w2[lin] = lin < per * 8 ? work[(lin & 7) * per + (lin >> 3)] : work[lin];
+			work.swap(w2);
+		}
 	}
 	if (res_rows >= (1LL << 30)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: too many rows in one call; split the pair list"); }
 	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
