@@ -15,6 +15,8 @@
 // only RANK candidates; the reference's float arithmetic decides every match.
 #include "internal.hpp"
 #include <cfloat>
+#include <cstring>
+#include <memory>
 #include <algorithm>
 
 struct op_features;   // sift_host.hip
@@ -48,16 +50,6 @@ struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; };
 
 constexpr int YP = 132;   // LDS pitch of a Y tile row (floats): 16-B slot rotation -> conflict-free b128
 
-__global__ void __launch_bounds__(256) k_norms(const float* desc, long long total, float* norms, unsigned* gmax_bits) {
-	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-	if (i >= total) return;
-	const f32x4* p = (const f32x4*)(desc + i * 128);
-	float s = 0.f;
-	for (int t = 0; t < 32; ++t) { f32x4 v = p[t]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-	norms[i] = s;
-	if (s == s) atomicMax(gmax_bits, __float_as_uint(s));     // a NaN descriptor must not poison the margin of every row
-}
-
 // Two-term bf16 split of every descriptor, row r -> [128 x hi][128 x lo] (512 B): hi = bf16(v)
 // (round to nearest even), lo = bf16(v - hi); v - hi is exact in fp32, so |v - hi - lo| <= 2^-18 |v|.
 // NaN stays NaN in both terms (such a row / column must simply never rank).
@@ -65,13 +57,28 @@ __device__ __forceinline__ unsigned bf16_rn(float v) {
 	const unsigned u = __float_as_uint(v);
 	return v != v ? 0x7fc0u : (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ desc, long long total, uint4* __restrict__ split) {
-	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 8 consecutive elements
-	if (i >= total * 16) return;
+// The same pass writes |row|^2 (16 threads per row, shuffle tree) and the maximum norm of the call.
+__global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ desc, long long total, uint4* __restrict__ split,
+		float* __restrict__ norms, unsigned* __restrict__ gmax_bits) {
+	long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 8 consecutive elements
+	const bool live = i < total * 16;
+	if (!live) i = total * 16 - 1;
 	const long long row = i >> 4; const int c = (int)(i & 15);
 	const f32x4* p = (const f32x4*)(desc + row * 128 + c * 8);
 	const f32x4 a = p[0], b = p[1];
 	const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	float sq = 0.f;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
+#pragma unroll
+	for (int d = 1; d < 16; d <<= 1) sq += __shfl_xor(sq, d);
+	if (live && c == 0) {
+		norms[row] = sq;
+		// a NaN descriptor must not poison the margin of every row; the plain read first
+		// keeps all but the first few rows off the single contended address
+		if (sq == sq && __float_as_uint(sq) > *(volatile unsigned*)gmax_bits) atomicMax(gmax_bits, __float_as_uint(sq));
+	}
+	if (!live) return;
 	unsigned hi[8], lo[8];
 #pragma unroll
 	for (int e = 0; e < 8; ++e) { hi[e] = bf16_rn(v[e]); lo[e] = bf16_rn(v[e] - __uint_as_float(hi[e] << 16)); }
@@ -123,7 +130,8 @@ struct MatchState {
 	int* surv;          // per pair region (res_off .. res_off+ka): A rows that passed the first ratio test
 	int* nsurv;         // per pair
 	int* mlist;         // accepted matches: [0] = count, then (pair, a, b) triples in arrival order
-	int* slow_fwd; int* slow_rev;   // rows needing a full scan: [0] = count, then (pair, row) pairs
+	int* slow_fwd; int* slow_rev;   // rows needing a full scan: (pair, row) pairs ...
+	int* slow_fwd_n; int* slow_rev_n;   // ... and their counts
 	int slow_cap;
 	float rr;           // MATCH_REJECT_NEXT_RATIO^2 (matcher.cc:16)
 };
@@ -336,8 +344,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	if (h == 1 && live) {
 		if (overflow) {
 			int* q = REV ? S.slow_rev : S.slow_fwd;
-			const int slot = atomicAdd(&q[0], 1);
-			if (slot < S.slow_cap) { q[1 + 2 * slot] = wk.pair; q[2 + 2 * slot] = a_row; }
+			const int slot = atomicAdd(REV ? S.slow_rev_n : S.slow_fwd_n, 1);
+			if (slot < S.slow_cap) { q[2 * slot] = wk.pair; q[2 * slot + 1] = a_row; }
 			if (!REV) S.fb[pd.res_off + a_row] = -2;
 		} else if (REV) finish_reverse(S, pd, wk.pair, a_row, next_min);
 		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
@@ -351,10 +359,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 template <bool REV>
 __global__ void __launch_bounds__(64) k_match_slow(MatchState S) {
 	const int* q = REV ? S.slow_rev : S.slow_fwd;
-	int n = q[0]; n = n < S.slow_cap ? n : S.slow_cap;
+	int n = *(REV ? S.slow_rev_n : S.slow_fwd_n); n = n < S.slow_cap ? n : S.slow_cap;
 	const int lane = threadIdx.x;
 	for (int i = blockIdx.x; i < n; i += gridDim.x) {
-		const int pair = q[1 + 2 * i], a = q[2 + 2 * i];
+		const int pair = q[2 * i], a = q[2 * i + 1];
 		const PairDesc pd = S.pairs[pair];
 		const float* A = S.desc + (long long)pd.a_off * 128;
 		const float* B = S.desc + (long long)pd.b_off * 128;
@@ -398,6 +406,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	m->npairs = npairs; m->pairs.resize(npairs);
 	if (npairs == 0 || total == 0) { *out = m; return OP_OK; }
 
+	std::unique_ptr<HostScope> hs(new HostScope(ctx, "matcher work list + launches (host)"));
 	std::vector<WorkItem> work;
 	std::vector<PairDesc> pds(npairs);
 	long long res_rows = 0;
@@ -429,65 +438,78 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
 	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
-	float *d_norms = nullptr, *d_fmn = nullptr, *d_fnext = nullptr; uint4* d_split = nullptr;
-	int *d_fb = nullptr, *d_surv = nullptr, *d_nsurv = nullptr, *d_mlist = nullptr, *d_slow = nullptr; unsigned* d_gmax = nullptr;
-	WorkItem* d_work = nullptr; PairDesc* d_pds = nullptr;
+	// One device arena, one memset, one upload per call (every runtime call costs microseconds and
+	// this function used to make about thirty).  Layout: a control block of counters that ends in
+	// the head of the accepted-match list -- so the zero-fill is one range and the result copy
+	// starts at the list's count -- followed by the per-call arrays.
 	// accepted matches come back as one packed list (count + triples); the first copy takes a
 	// head of kHead entries, which covers the usual few percent of rows, a second one the rest
-	const size_t kHead = std::min<size_t>(nres, 1 << 16);
-	int* h_ml = (int*)ctx->pinned_scratch(sizeof(int) * (1 + 3 * nres));     // pinned: the D2H runs at link rate
+	const size_t kHead = std::min<size_t>(nres, 1 << 14);
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const size_t n_ctrl = 3 + (size_t)npairs + 1;                      // gmax, slow_fwd_n, slow_rev_n, nsurv[npairs], mlist count
+	const size_t o_ctrl = 0;
+	const size_t o_trip = sizeof(int) * n_ctrl;                        // triples follow the count directly
+	const size_t o_norms = al(o_trip + sizeof(int) * 3 * nres);
+	const size_t o_split = al(o_norms + sizeof(float) * total);
+	const size_t o_fmn = al(o_split + 512 * (size_t)total);
+	const size_t o_fnext = al(o_fmn + sizeof(float) * nres);
+	const size_t o_fb = al(o_fnext + sizeof(float) * nres);
+	const size_t o_surv = al(o_fb + sizeof(int) * nres);
+	const size_t o_slow = al(o_surv + sizeof(int) * nres);
+	const size_t o_up = al(o_slow + sizeof(int) * 4 * (size_t)slow_cap);
+	const size_t up_bytes = sizeof(PairDesc) * npairs + sizeof(WorkItem) * work.size();
+	const size_t arena_bytes = o_up + al(up_bytes);
+	char* arena = nullptr;
+	const size_t hml_bytes = al(sizeof(int) * (1 + 3 * nres));
+	char* pin = (char*)ctx->pinned_scratch(hml_bytes + up_bytes);          // pinned: copies run at link rate, asynchronously
 	int rc = OP_OK;
-	if (!h_ml) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
+	if (!pin) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
+	int* h_ml = (int*)pin;
+	std::memcpy(pin + hml_bytes, pds.data(), sizeof(PairDesc) * npairs);
+	if (!work.empty()) std::memcpy(pin + hml_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
-	MCHK(pool_alloc((void**)&d_norms, sizeof(float) * total));
-	MCHK(pool_alloc((void**)&d_split, 512 * (size_t)total));
-	MCHK(pool_alloc((void**)&d_gmax, sizeof(unsigned)));
-	MCHK(pool_alloc((void**)&d_fmn, sizeof(float) * nres));
-	MCHK(pool_alloc((void**)&d_fnext, sizeof(float) * nres));
-	MCHK(pool_alloc((void**)&d_fb, sizeof(int) * nres));
-	MCHK(pool_alloc((void**)&d_surv, sizeof(int) * nres));
-	MCHK(pool_alloc((void**)&d_nsurv, sizeof(int) * npairs));
-	MCHK(pool_alloc((void**)&d_mlist, sizeof(int) * (1 + 3 * nres)));
-	MCHK(pool_alloc((void**)&d_slow, sizeof(int) * 2 * (1 + 2 * (size_t)slow_cap)));
-	MCHK(pool_alloc((void**)&d_work, sizeof(WorkItem) * std::max<size_t>(work.size(), 1)));
-	MCHK(pool_alloc((void**)&d_pds, sizeof(PairDesc) * npairs));
-	MCHK(hipMemsetAsync(d_gmax, 0, sizeof(unsigned), st));
-	MCHK(hipMemsetAsync(d_nsurv, 0, sizeof(int) * npairs, st));
-	MCHK(hipMemsetAsync(d_mlist, 0, sizeof(int), st));
-	MCHK(hipMemsetAsync(d_slow, 0, sizeof(int), st));
-	MCHK(hipMemsetAsync(d_slow + 1 + 2 * (size_t)slow_cap, 0, sizeof(int), st));
-	if (!work.empty()) MCHK(hipMemcpyAsync(d_work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
-	MCHK(hipMemcpyAsync(d_pds, pds.data(), sizeof(PairDesc) * npairs, hipMemcpyHostToDevice, st));
+	MCHK(pool_alloc((void**)&arena, arena_bytes));
 	{
-		ProfScope ps(ctx, "matcher norms");
-		hipLaunchKernelGGL(k_norms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, fv.desc, total, d_norms, d_gmax);
-		MCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, fv.desc, total, d_split);
-		MCHK(hipGetLastError());
-	}
-	if (!work.empty()) {
+		int* ctrl = (int*)(arena + o_ctrl);
+		int* d_mlist = ctrl + 3 + npairs;                              // [count][triples ...]
+		MCHK(hipMemsetAsync(ctrl, 0, sizeof(int) * n_ctrl, st));
+		MCHK(hipMemcpyAsync(arena + o_up, pin + hml_bytes, up_bytes, hipMemcpyHostToDevice, st));
 		MatchState S;
-		S.desc = fv.desc; S.split = d_split; S.norms = d_norms; S.gmax_bits = d_gmax; S.pairs = d_pds;
-		S.fb = d_fb; S.fmn = d_fmn; S.fnext = d_fnext; S.surv = d_surv; S.nsurv = d_nsurv; S.mlist = d_mlist;
-		S.slow_fwd = d_slow; S.slow_rev = d_slow + 1 + 2 * (size_t)slow_cap; S.slow_cap = slow_cap;
+		S.desc = fv.desc; S.split = (const uint4*)(arena + o_split); S.norms = (const float*)(arena + o_norms);
+		S.gmax_bits = (const unsigned*)ctrl; S.pairs = (const PairDesc*)(arena + o_up);
+		S.fb = (int*)(arena + o_fb); S.fmn = (float*)(arena + o_fmn); S.fnext = (float*)(arena + o_fnext);
+		S.surv = (int*)(arena + o_surv); S.nsurv = ctrl + 3; S.mlist = d_mlist;
+		S.slow_fwd = (int*)(arena + o_slow); S.slow_rev = S.slow_fwd + 2 * (size_t)slow_cap;
+		S.slow_fwd_n = ctrl + 1; S.slow_rev_n = ctrl + 2; S.slow_cap = slow_cap;
 		S.rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
+		const WorkItem* d_work = (const WorkItem*)(arena + o_up + sizeof(PairDesc) * npairs);
 		{
-			ProfScope ps(ctx, "matcher mfma forward");
-			hipLaunchKernelGGL(k_match_sweep<false>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
-			MCHK(hipGetLastError());
-			hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(64), 0, st, S);
+			ProfScope ps(ctx, "matcher norms");
+			hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, fv.desc, total,
+					(uint4*)(arena + o_split), (float*)(arena + o_norms), (unsigned*)ctrl);
 			MCHK(hipGetLastError());
 		}
-		{
-			// the reverse strip: same work list; row blocks beyond a pair's survivor count exit at once
-			ProfScope ps(ctx, "matcher mfma reverse");
-			hipLaunchKernelGGL(k_match_sweep<true>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
-			MCHK(hipGetLastError());
-			hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(64), 0, st, S);
-			MCHK(hipGetLastError());
+		if (!work.empty()) {
+			{
+				ProfScope ps(ctx, "matcher mfma forward");
+				hipLaunchKernelGGL(k_match_sweep<false>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
+				MCHK(hipGetLastError());
+				hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(64), 0, st, S);
+				MCHK(hipGetLastError());
+			}
+			{
+				// the reverse strip: same work list; row blocks beyond a pair's survivor count exit at once
+				ProfScope ps(ctx, "matcher mfma reverse");
+				hipLaunchKernelGGL(k_match_sweep<true>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
+				MCHK(hipGetLastError());
+				hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(64), 0, st, S);
+				MCHK(hipGetLastError());
+			}
 		}
 	}
+	int* d_mlist; d_mlist = (int*)(arena + o_ctrl) + 3 + npairs;
 	h_ml[0] = 0;
+	hs.reset(); hs.reset(new HostScope(ctx, "matcher wait + result copy (host)"));
 	if (!work.empty()) {
 		MCHK(hipMemcpyAsync(h_ml, d_mlist, sizeof(int) * (1 + 3 * kHead), hipMemcpyDeviceToHost, st));
 		MCHK(hipStreamSynchronize(st));
@@ -497,30 +519,38 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		}
 	} else MCHK(hipStreamSynchronize(st));
 	resolve_profile(ctx);
+	hs.reset(); hs.reset(new HostScope(ctx, "matcher result lists (host)"));
 	{
+		// counting sort of the (pair, a, b) triples by pair into one flat array, then every pair's
+		// slice is put into the reference's <first, second> form and sorted (arrival order on the
+		// device is arbitrary) -- the per-pair part runs on the host pool
 		const int nm = h_ml[0];
-		std::vector<int> cnt(npairs, 0);
-		for (int e = 0; e < nm; ++e) ++cnt[h_ml[1 + 3 * e]];
-		for (int p = 0; p < npairs; ++p) m->pairs[p].reserve(2 * (size_t)cnt[p]);
-		for (int e = 0; e < nm; ++e) {
-			const int* q = h_ml + 1 + 3 * (size_t)e;
-			std::vector<int>& v = m->pairs[q[0]];
-			if (pds[q[0]].rev) { v.push_back(q[2]); v.push_back(q[1]); }        // pairs are <b, a> (matcher.cc:68-69)
-			else { v.push_back(q[1]); v.push_back(q[2]); }
-		}
-		for (int p = 0; p < npairs; ++p) {         // arrival order is arbitrary: sort by (first, second)
-			std::vector<int>& v = m->pairs[p];
-			const size_t k = v.size() / 2;
-			if (k > 1) {
-				std::pair<int, int>* pp = reinterpret_cast<std::pair<int, int>*>(v.data());
-				std::sort(pp, pp + k);
+		std::vector<int> start(npairs + 1, 0);
+		for (int e = 0; e < nm; ++e) ++start[h_ml[1 + 3 * (size_t)e] + 1];
+		for (int p = 0; p < npairs; ++p) start[p + 1] += start[p];
+		std::vector<std::pair<int, int>> flat((size_t)nm);
+		{
+			std::vector<int> fill(start.begin(), start.end() - 1);
+			for (int e = 0; e < nm; ++e) {
+				const int* q = h_ml + 1 + 3 * (size_t)e;
+				flat[(size_t)fill[q[0]]++] = pds[q[0]].rev ? std::make_pair(q[2], q[1]) : std::make_pair(q[1], q[2]);   // <b, a> when swapped (matcher.cc:68-69)
 			}
-			m->total += (int64_t)k;
 		}
+		const int chunk = 32, nchunks = (npairs + chunk - 1) / chunk;
+		host_parallel_for(nchunks, [&](int c) {
+			for (int p = c * chunk; p < std::min(npairs, (c + 1) * chunk); ++p) {
+				std::pair<int, int>* b0 = flat.data() + start[p]; std::pair<int, int>* b1 = flat.data() + start[p + 1];
+				if (b1 - b0 > 1) std::sort(b0, b1);
+				std::vector<int>& v = m->pairs[p];
+				v.resize(2 * (size_t)(b1 - b0));
+				for (std::pair<int, int>* it = b0; it != b1; ++it) { v[2 * (it - b0)] = it->first; v[2 * (it - b0) + 1] = it->second; }
+			}
+		});
+		m->total = nm;
 	}
 done:
-	pool_free(d_norms); pool_free(d_split); pool_free(d_gmax); pool_free(d_fmn); pool_free(d_fnext); pool_free(d_fb); pool_free(d_surv);
-	pool_free(d_nsurv); pool_free(d_mlist); pool_free(d_slow); pool_free(d_work); pool_free(d_pds);
+	hs.reset();
+	pool_free(arena);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
 	*out = m;
