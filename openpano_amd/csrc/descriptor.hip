@@ -48,9 +48,8 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 	long long total = img_offset[p.n];                 // device-side count (k_image_offsets)
 	total = total < cap ? total : cap;                 // speculative capacity: the host re-runs on overflow
 	for (long long kk = blockIdx.x; kk < total; kk += gridDim.x) {
-		int img = 0;
-		while (img + 1 < p.n && kk >= img_offset[img + 1]) ++img;
 		const KeyPoint kp = oriented[kk];
+		const int img = kp.pad;                            // written by k_expand_oriented
 		const OctDesc od = p.oct[kp.oct];
 		const int w = od.w, h = od.h;
 		const float* base = p.ws + (long long)img * p.ws_stride;
@@ -195,7 +194,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset,
 		long long cap, float* desc, double* coor, double* real, hipStream_t st) {
 	if (cap <= 0) return hipSuccess;
-	const int grid = (int)(cap < 32768 ? cap : 32768);          // wavefronts beyond the device-side count exit at once
+	const int grid = (int)(cap < (1 << 20) ? cap : (1 << 20));  // one keypoint per wavefront; wavefronts beyond the device-side count exit at once
 	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, cap, desc, coor, real);
 	return hipGetLastError();
 }

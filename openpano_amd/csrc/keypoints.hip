@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined
 			KeyPoint kp = refined[(long long)img * cap + i];
 			const float* d = dirs + ((long long)img * cap + i) * ORI_BINS;
 			for (int j = 0; j < cnt; ++j) {
-				kp.dir = d[j]; kp.src = i;
+				kp.dir = d[j]; kp.src = i; kp.pad = img;      // pad carries the image index to the descriptor kernel
 				const long long slot = img_offset[img] + excl + j;
 				if (slot < oriented_cap) oriented[slot] = kp;       // speculative capacity: the host re-runs on overflow
 			}
