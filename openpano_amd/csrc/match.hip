@@ -57,35 +57,43 @@ __device__ __forceinline__ unsigned bf16_rn(float v) {
 	const unsigned u = __float_as_uint(v);
 	return v != v ? 0x7fc0u : (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-// The same pass writes |row|^2 (16 threads per row, shuffle tree) and the maximum norm of the call.
+// The same pass writes |row|^2 (16 threads per row, shuffle tree) and the maximum norm of the call
+// (grid-stride loop, one atomic per workgroup: tens of thousands of atomics on one address cost more
+// than the whole split).
 __global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ desc, long long total, uint4* __restrict__ split,
 		float* __restrict__ norms, unsigned* __restrict__ gmax_bits) {
-	long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread = 8 consecutive elements
-	const bool live = i < total * 16;
-	if (!live) i = total * 16 - 1;
-	const long long row = i >> 4; const int c = (int)(i & 15);
-	const f32x4* p = (const f32x4*)(desc + row * 128 + c * 8);
-	const f32x4 a = p[0], b = p[1];
-	const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-	float sq = 0.f;
+	__shared__ unsigned s_max[4];
+	unsigned mymax = 0u;                                       // norms are >= 0: their bit patterns order like the values
+	const long long nthreads = total * 16, stride = (long long)gridDim.x * 256;
+	for (long long i0 = (long long)blockIdx.x * 256; i0 < nthreads; i0 += stride) {      // one thread = 8 consecutive elements
+		long long i = i0 + threadIdx.x;
+		const bool live = i < nthreads;
+		if (!live) i = nthreads - 1;
+		const long long row = i >> 4; const int c = (int)(i & 15);
+		const f32x4* p = (const f32x4*)(desc + row * 128 + c * 8);
+		const f32x4 a = p[0], b = p[1];
+		const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+		float sq = 0.f;
 #pragma unroll
-	for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
+		for (int e = 0; e < 8; ++e) sq += v[e] * v[e];
 #pragma unroll
-	for (int d = 1; d < 16; d <<= 1) sq += __shfl_xor(sq, d);
-	if (live && c == 0) {
-		norms[row] = sq;
-		// a NaN descriptor must not poison the margin of every row; the plain read first
-		// keeps all but the first few rows off the single contended address
-		if (sq == sq && __float_as_uint(sq) > *(volatile unsigned*)gmax_bits) atomicMax(gmax_bits, __float_as_uint(sq));
+		for (int d = 1; d < 16; d <<= 1) sq += __shfl_xor(sq, d);
+		if (live && c == 0) norms[row] = sq;
+		if (sq == sq) mymax = max(mymax, __float_as_uint(sq));   // a NaN descriptor must not poison the margin of every row
+		if (!live) continue;
+		unsigned hi[8], lo[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) { hi[e] = bf16_rn(v[e]); lo[e] = bf16_rn(v[e] - __uint_as_float(hi[e] << 16)); }
+		uint4 H, L;
+		H.x = hi[0] | (hi[1] << 16); H.y = hi[2] | (hi[3] << 16); H.z = hi[4] | (hi[5] << 16); H.w = hi[6] | (hi[7] << 16);
+		L.x = lo[0] | (lo[1] << 16); L.y = lo[2] | (lo[3] << 16); L.z = lo[4] | (lo[5] << 16); L.w = lo[6] | (lo[7] << 16);
+		split[row * 32 + c] = H; split[row * 32 + 16 + c] = L;
 	}
-	if (!live) return;
-	unsigned hi[8], lo[8];
 #pragma unroll
-	for (int e = 0; e < 8; ++e) { hi[e] = bf16_rn(v[e]); lo[e] = bf16_rn(v[e] - __uint_as_float(hi[e] << 16)); }
-	uint4 H, L;
-	H.x = hi[0] | (hi[1] << 16); H.y = hi[2] | (hi[3] << 16); H.z = hi[4] | (hi[5] << 16); H.w = hi[6] | (hi[7] << 16);
-	L.x = lo[0] | (lo[1] << 16); L.y = lo[2] | (lo[3] << 16); L.z = lo[4] | (lo[5] << 16); L.w = lo[6] | (lo[7] << 16);
-	split[row * 32 + c] = H; split[row * 32 + 16 + c] = L;
+	for (int d = 1; d < 64; d <<= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, d));
+	if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mymax;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicMax(gmax_bits, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 }
 
 // running top-NK (descending score); the common case is the single rejecting compare.  NK = 4:
@@ -485,7 +493,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		const WorkItem* d_work = (const WorkItem*)(arena + o_up + sizeof(PairDesc) * npairs);
 		{
 			ProfScope ps(ctx, "matcher norms");
-			hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, fv.desc, total,
+			hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)std::min<long long>((total * 16 + 255) / 256, 1024)), dim3(256), 0, st, fv.desc, total,
 					(uint4*)(arena + o_split), (float*)(arena + o_norms), (unsigned*)ctrl);
 			MCHK(hipGetLastError());
 		}
