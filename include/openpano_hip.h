@@ -157,7 +157,7 @@ int op_debug_math(op_ctx* ctx, int which, const float* x, const float* y, int n,
  * Stitcher::pairwise_match / linear_pairwise_match (stitch/stitcher.cc:96-136), with the
  * semantics of the reference's exact matcher FeatureMatcher::match (matcher.cc:15-71): 2-NN
  * ratio test from the smaller set, then the reverse test.  All requested pairs are
- * matched in one launch series; fp32 MFMA tiles rank candidates, an exact re-score in the
+ * matched in one launch series; MFMA tiles (two-term bf16 split, fp32 accumulate) rank candidates, an exact re-score in the
  * reference's summation order (feature/dist.cc:22-57) decides.
  * ===================================================================================== */
 typedef struct op_matches op_matches;
