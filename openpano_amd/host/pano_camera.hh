@@ -1,0 +1,524 @@
+// pano_camera.hh -- host-side camera estimation and bundle adjustment without Eigen
+// (SURVEY 8(f).2): the step of Stitcher::build() between the device-side match/RANSAC stage and
+// the device-side blend, under ESTIMATE_CAMERA (BASELINE configs 2-4).  Same classes, members and
+// call order as the reference so that code written against it compiles unchanged:
+//   Camera                        stitch/camera.hh:12-49, stitch/camera.cc:19-183
+//   IncrementalBundleAdjuster     stitch/incremental_bundle_adjuster.hh:20-120, .cc:19-417
+//   CameraEstimator               stitch/camera_estimator.hh, .cc:21-160
+// Linear algebra comes from pano_la.hh (3x3 SVD / inverse, column-pivoted QR solve) where the
+// reference calls Eigen.  Differences by construction, results unchanged:
+//   * the Jacobian J (2M x 6n, up to 700 000 rows, whose setZero() the reference's author measured
+//     at a third of the time, incremental_bundle_adjuster.cc:280) is never materialised: J^T r is
+//     accumulated term by term in the same order a dense row-by-row product visits the non-zeros
+//     (the zeros of J contribute exact zeros), JtJ exactly as the reference accumulates it;
+//   * only the analytic Jacobian (SYMBOLIC_DIFF = true, :22) is provided.
+// Used standalone (pano_types.hh); with -DOPENPANO_WITH_REFERENCE the reference's own classes
+// are in scope instead and this header is not included.
+#pragma once
+#include <array>
+#include <cmath>
+#include <functional>
+#include <limits>
+#include <queue>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "pano_types.hh"
+
+namespace pano {
+
+[[noreturn]] inline void pano_error_exit(const std::string& msg) {      // lib/debugutils.cc:57-60
+	fprintf(stderr, "error: %s\n", msg.c_str());
+	exit(1);
+}
+
+constexpr double PANO_EPS = 1e-6, PANO_GEO_EPS = 1e-7, PANO_GEO_EPS_SQR = 1e-14;   // lib/utils.hh:22-24
+// lib/utils.hh:25 -- the reference's only sqr() takes and returns FLOAT: the two places of the bundle
+// adjuster that call it on doubles (the error statistic, incremental_bundle_adjuster.cc:202, and
+// 1/z^2 of the projection derivative, :309) round through fp32, and so do these
+inline float pano_sqr(float x) { return x * x; }
+
+class Camera {
+	public:
+		double focal = 1, aspect = 1, ppx = 0, ppy = 0;
+		Homography R = Homography::I();
+
+		Homography K() const {                                  // camera.cc:59-66
+			Homography ret = Homography::I();
+			ret[0] = focal; ret[2] = ppx; ret[4] = focal * aspect; ret[5] = ppy;
+			return ret;
+		}
+		Homography Kinv() const { return K().inverse(); }
+		Homography Rinv() const { return R.transpose(); }
+
+		// Szeliski, "Creating Full View Panoramic Image Mosaics" (camera.cc:19-53)
+		static double get_focal_from_matrix(const Homography& h) {
+			double d1, d2, v1, v2, f1, f0;
+			d1 = h[6] * h[7];
+			d2 = (h[7] - h[6]) * (h[7] + h[6]);
+			v1 = -(h[0] * h[1] + h[3] * h[4]) / d1;
+			v2 = (h[0] * h[0] + h[3] * h[3] - h[1] * h[1] - h[4] * h[4]) / d2;
+			if (v1 < v2) std::swap(v1, v2);
+			if (v1 > 0 && v2 > 0) f1 = sqrt(std::abs(d1) > std::abs(d2) ? v1 : v2);
+			else if (v1 > 0) f1 = sqrt(v1);
+			else return 0;
+			d1 = h[0] * h[3] + h[1] * h[4];
+			d2 = h[0] * h[0] + h[1] * h[1] - h[3] * h[3] - h[4] * h[4];
+			v1 = -h[2] * h[5] / d1;
+			v2 = (h[5] * h[5] - h[2] * h[2]) / d2;
+			if (v1 < v2) std::swap(v1, v2);
+			if (v1 > 0 && v2 > 0) f0 = sqrt(std::abs(d1) > std::abs(d2) ? v1 : v2);
+			else if (v1 > 0) f0 = sqrt(v1);
+			else return 0;
+			if (std::isinf(f1) || std::isinf(f0)) return 0;
+			return sqrt(f1 * f0);
+		}
+
+		// median of the per-pair estimates over confident pairs i < j (camera.cc:68-87)
+		static double estimate_focal(const std::vector<std::vector<MatchInfo>>& matches) {
+			const int n = (int)matches.size();
+			std::vector<double> estimates;
+			for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) {
+				const MatchInfo& match = matches[i][j];
+				if (match.confidence < PANO_EPS) continue;
+				estimates.emplace_back(get_focal_from_matrix(match.homo));
+			}
+			const int ne = (int)estimates.size();
+			if (ne < std::min(n - 1, 3)) return -1;
+			std::sort(estimates.begin(), estimates.end());
+			if (ne % 2 == 1) return estimates[ne >> 1];
+			return (estimates[ne >> 1] + estimates[(ne >> 1) - 1]) * 0.5;
+		}
+
+		// nearest rotation (U V^T of the SVD), then axis * angle (camera.cc:91-120)
+		static void rotation_to_angle(const Homography& r, double& rx, double& ry, double& rz) {
+			double U[9], S[3], V[9], Rn[9];
+			pano_la::jacobi_svd(r.data, 3, 3, U, S, V);
+			for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+				double s = 0;
+				for (int k = 0; k < 3; ++k) s += U[i * 3 + k] * V[j * 3 + k];      // U * V^T
+				Rn[i * 3 + j] = s;
+			}
+			if (pano_la::det3(Rn) < 0) for (int i = 0; i < 9; ++i) Rn[i] *= -1;
+			rx = Rn[7] - Rn[5];
+			ry = Rn[2] - Rn[6];
+			rz = Rn[3] - Rn[1];
+			const double s = sqrt(rx * rx + ry * ry + rz * rz);
+			if (s < PANO_GEO_EPS) { rx = ry = rz = 0; }
+			else {
+				double c = (Rn[0] + Rn[4] + Rn[8] - 1) * 0.5;
+				c = c > 1. ? 1. : c < -1. ? -1. : c;
+				const double theta = acos(c);
+				const double mul = 1.0 / s * theta;
+				rx *= mul; ry *= mul; rz *= mul;
+			}
+		}
+
+		// Rodrigues (camera.cc:123-147)
+		static void angle_to_rotation(double rx, double ry, double rz, Homography& r) {
+			double theta = rx * rx + ry * ry + rz * rz;
+			if (theta < PANO_GEO_EPS_SQR) {
+				const double t[9] = {1, -rz, ry, rz, 1, -rx, -ry, rx, 1};
+				r = Homography(t);
+				return;
+			}
+			theta = sqrt(theta);
+			const double itheta = theta ? 1. / theta : 0.;
+			rx *= itheta; ry *= itheta; rz *= itheta;
+			const double u_outp[] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+			const double u_crossp[] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+			r = Homography::I();
+			const double c = cos(theta), s = sin(theta), c1 = 1 - c;
+			r.mult(c);
+			for (int k = 0; k < 9; ++k) r[k] += c1 * u_outp[k] + s * u_crossp[k];
+		}
+
+		// wave correction: make the cameras' X axes orthogonal to a common up vector (camera.cc:149-183)
+		static void straighten(std::vector<Camera>& cameras) {
+			double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (auto& c : cameras) {
+				const double v[3] = {c.R[0], c.R[1], c.R[2]};
+				for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; s += v[i] * v[j]; cov[i * 3 + j] += s; }
+			}
+			double U[9], S[3], V[9];
+			pano_la::jacobi_svd(cov, 3, 3, U, S, V);
+			Vec normY(V[2], V[5], V[8]);                        // V.col(2)
+			Vec vz(0, 0, 0);
+			for (auto& c : cameras) { vz.x += c.R[6]; vz.y += c.R[7]; vz.z += c.R[8]; }
+			Vec normX = normY.cross(vz);
+			{
+				const double nn = sqrt(normX.x * normX.x + normX.y * normX.y + normX.z * normX.z);
+				normX.x /= nn; normX.y /= nn; normX.z /= nn;
+			}
+			Vec normZ = normX.cross(normY);
+			double s = 0;
+			for (auto& c : cameras) s += normX.dot(Vec(c.R[0], c.R[1], c.R[2]));
+			if (s < 0) { normX = normX * -1; normY = normY * -1; }
+			Homography r;
+			const double nx[3] = {normX.x, normX.y, normX.z}, ny[3] = {normY.x, normY.y, normY.z}, nz[3] = {normZ.x, normZ.y, normZ.z};
+			for (int i = 0; i < 3; ++i) { r[i * 3] = nx[i]; r[i * 3 + 1] = ny[i]; r[i * 3 + 2] = nz[i]; }
+			for (auto& c : cameras) c.R = c.R * r;
+		}
+};
+
+class IncrementalBundleAdjuster {
+	public:
+		struct ErrorStats {
+			std::vector<double> residuals;
+			double max = 0, avg = 0;
+			explicit ErrorStats(int size): residuals(size) {}
+			int num_terms() const { return (int)residuals.size(); }
+			void update_stats(int) {                           // :208-229 (squared error)
+				avg = max = 0;
+				for (auto& e : residuals) { avg += pano_sqr((float)e); if (fabs(e) > max) max = fabs(e); }
+				avg /= residuals.size();
+				avg = sqrt(avg);
+			}
+		};
+
+		explicit IncrementalBundleAdjuster(std::vector<Camera>& cameras): result_cameras(cameras), index_map(cameras.size()) {}
+		IncrementalBundleAdjuster(const IncrementalBundleAdjuster&) = delete;
+		IncrementalBundleAdjuster& operator=(const IncrementalBundleAdjuster&) = delete;
+
+		// m is matches[j][i] in the stitcher, i.e. from i to j (:116-123)
+		void add_match(int i, int j, const MatchInfo& m) {
+			match_pairs.emplace_back(i, j, m);
+			match_cnt_prefix_sum.emplace_back(nr_pointwise_match);
+			nr_pointwise_match += (int)m.match.size();
+			idx_added.insert(i); idx_added.insert(j);
+		}
+		void set_identity_idx(int idx) { identity_idx = idx; }
+
+		ErrorStats get_error_stat() {
+			ParamState state;
+			for (auto& c : result_cameras) state.cameras.emplace_back(c);
+			state.ensure_params();
+			return calcError(state);
+		}
+
+		// Levenberg-Marquardt with the acceptance rule of :125-177
+		void optimize() {
+			if (idx_added.empty()) pano_error_exit("Calling optimize() without adding any matches!");
+			update_index_map();
+			const int nr_img = (int)idx_added.size();
+			JtJ.assign((size_t)(NR_PARAM_PER_CAMERA * nr_img) * (NR_PARAM_PER_CAMERA * nr_img), 0.0);
+			Jtr.assign((size_t)NR_PARAM_PER_CAMERA * nr_img, 0.0);
+			ParamState state;
+			for (auto& idx : idx_added) state.cameras.emplace_back(result_cameras[idx]);
+			state.ensure_params();
+			state.cameras.clear();          // the cameras are re-derived from the parameter vector, like the reference
+			ErrorStats err_stat = calcError(state);
+			double best_err = err_stat.avg;
+			int itr = 0, nr_non_decrease = 0;
+			inlier_threshold = std::numeric_limits<int>::max();
+			const size_t idt = index_map[identity_idx];
+			while (itr++ < LM_MAX_ITER) {
+				const std::vector<double> update = get_param_update(state, err_stat.residuals, config::LM_LAMBDA);
+				ParamState new_state;
+				new_state.params = state.get_params();
+				for (size_t i = 0; i < new_state.params.size(); ++i)
+					if (i < idt * 6 + 3 || i >= idt * 6 + 6) new_state.params[i] -= update[i];     // R of the identity image stays
+				err_stat = calcError(new_state);
+				if (err_stat.avg >= best_err - 1e-3) nr_non_decrease++;
+				else { nr_non_decrease = 0; best_err = err_stat.avg; state = std::move(new_state); }
+				if (nr_non_decrease > 5) break;
+			}
+			last_error = best_err; last_iterations = itr;
+			auto results = state.get_cameras();
+			int now = 0;
+			for (auto& i : idx_added) result_cameras[i] = results[now++];
+		}
+		double last_error = 0; int last_iterations = 0;
+
+	protected:
+		static constexpr int NR_PARAM_PER_CAMERA = 6, NR_TERM_PER_MATCH = 2, LM_MAX_ITER = 100;
+		std::vector<Camera>& result_cameras;
+		struct MatchPair {
+			int from, to;
+			const MatchInfo& m;
+			MatchPair(int i, int j, const MatchInfo& m): from(i), to(j), m(m) {}
+		};
+		int nr_pointwise_match = 0;
+		int inlier_threshold = std::numeric_limits<int>::max();
+		std::vector<MatchPair> match_pairs;
+		int identity_idx = -1;
+		std::set<int> idx_added;
+		std::vector<int> index_map, match_cnt_prefix_sum;
+		void update_index_map() { int cnt = 0; for (auto& i : idx_added) index_map[i] = cnt++; }
+
+		struct ParamState {
+			std::vector<Camera> cameras;
+			std::vector<double> params;
+			std::vector<Camera>& get_cameras() {               // :387-395
+				if (cameras.size()) return cameras;
+				cameras.resize(params.size() / NR_PARAM_PER_CAMERA);
+				for (size_t i = 0; i < cameras.size(); ++i) params_to_camera(params.data() + i * NR_PARAM_PER_CAMERA, cameras[i]);
+				return cameras;
+			}
+			const std::vector<Camera>& get_cameras() const { return const_cast<ParamState*>(this)->get_cameras(); }
+			void ensure_params() const {                        // :397-406
+				if (params.size()) return;
+				std::vector<double>& p = const_cast<std::vector<double>&>(params);
+				p.resize(cameras.size() * NR_PARAM_PER_CAMERA);
+				for (size_t i = 0; i < cameras.size(); ++i) camera_to_params(cameras[i], p.data() + i * NR_PARAM_PER_CAMERA);
+			}
+			const std::vector<double>& get_params() const { ensure_params(); return params; }
+		};
+		static void camera_to_params(const Camera& c, double* ptr) {   // :27-32
+			ptr[0] = c.focal; ptr[1] = c.ppx; ptr[2] = c.ppy;
+			Camera::rotation_to_angle(c.R, ptr[3], ptr[4], ptr[5]);
+		}
+		static void params_to_camera(const double* ptr, Camera& c) {   // :34-40
+			c.focal = ptr[0]; c.ppx = ptr[1]; c.ppy = ptr[2]; c.aspect = 1;
+			Camera::angle_to_rotation(ptr[3], ptr[4], ptr[5], c.R);
+		}
+		static Homography cross_product_matrix(double x, double y, double z) {
+			const double t[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+			return Homography(t);
+		}
+		// dR/dv_i, Gallego & Yezzi, "A compact formula for the derivative of a 3-D rotation in
+		// exponential coordinates" (:48-83)
+		static std::array<Homography, 3> dRdvi(const Homography& R) {
+			double v[3];
+			Camera::rotation_to_angle(R, v[0], v[1], v[2]);
+			const Vec vvec(v[0], v[1], v[2]);
+			const double vsqr = vvec.sqr();
+			if (vsqr < PANO_GEO_EPS_SQR)
+				return std::array<Homography, 3>{cross_product_matrix(1, 0, 0), cross_product_matrix(0, 1, 0), cross_product_matrix(0, 0, 1)};
+			const Homography r = cross_product_matrix(v[0], v[1], v[2]);
+			std::array<Homography, 3> ret{r, r, r};
+			for (int i = 0; i < 3; ++i) ret[i].mult(v[i]);
+			Vec I_R_e(1 - R.data[0], -R.data[3], -R.data[6]);
+			I_R_e = vvec.cross(I_R_e);
+			ret[0] += cross_product_matrix(I_R_e.x, I_R_e.y, I_R_e.z);
+			I_R_e = Vec(-R.data[1], 1 - R.data[4], -R.data[7]);
+			I_R_e = vvec.cross(I_R_e);
+			ret[1] += cross_product_matrix(I_R_e.x, I_R_e.y, I_R_e.z);
+			I_R_e = Vec(-R.data[2], -R.data[5], 1 - R.data[8]);
+			I_R_e = vvec.cross(I_R_e);
+			ret[2] += cross_product_matrix(I_R_e.x, I_R_e.y, I_R_e.z);
+			for (int i = 0; i < 3; ++i) { ret[i].mult(1.0 / vsqr); ret[i] = ret[i] * R; }
+			return ret;
+		}
+
+		std::vector<double> JtJ, Jtr;       // (6n)^2 and 6n, kept across iterations
+
+		ErrorStats calcError(const ParamState& state) {            // :179-206
+			ErrorStats ret(nr_pointwise_match * NR_TERM_PER_MATCH);
+			auto cameras = state.get_cameras();
+			int idx = 0;
+			for (auto& pair : match_pairs) {
+				const int from = index_map[pair.from], to = index_map[pair.to];
+				auto& c_from = cameras[from]; auto& c_to = cameras[to];
+				const Homography Hto_to_from = (c_from.K() * c_from.R) * (c_to.Rinv() * c_to.K().inverse());
+				for (const auto& p : pair.m.match) {
+					const Vec2D to2 = p.first, from2 = p.second;
+					const Vec2D transformed = Hto_to_from.trans2d(to2);
+					ret.residuals[idx] = from2.x - transformed.x;
+					ret.residuals[idx + 1] = from2.y - transformed.y;
+					idx += 2;
+				}
+			}
+			ret.update_stats(inlier_threshold);
+			return ret;
+		}
+
+		// (JtJ + damping) x = J^T r  (:231-251)
+		std::vector<double> get_param_update(const ParamState& state, const std::vector<double>& residual, float lambda) {
+			const int nr_img = (int)idx_added.size(), np = nr_img * NR_PARAM_PER_CAMERA;
+			calcJacobianSymbolic(state, residual);
+			for (int i = 0; i < np; ++i) {
+				if (i % NR_PARAM_PER_CAMERA >= 3) JtJ[(size_t)i * np + i] += lambda;
+				else JtJ[(size_t)i * np + i] += lambda / 10.f;
+			}
+			std::vector<double> x(np, 0.0);
+			pano_la::colpiv_qr_solve(JtJ.data(), np, Jtr.data(), x.data());
+			return x;
+		}
+
+		// Analytic derivatives of the residuals (Brown & Lowe, IJCV'07, section 4) -> JtJ and J^T r (:276-385)
+		void calcJacobianSymbolic(const ParamState& state, const std::vector<double>& residual) {
+			const int np = (int)idx_added.size() * NR_PARAM_PER_CAMERA;
+			std::fill(JtJ.begin(), JtJ.end(), 0.0);
+			std::fill(Jtr.begin(), Jtr.end(), 0.0);
+			const auto& cameras = state.get_cameras();
+			std::vector<std::array<Homography, 3>> all_dRdvi(cameras.size());
+			for (size_t i = 0; i < cameras.size(); ++i) all_dRdvi[i] = dRdvi(cameras[i].R);
+			const double kf[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0}, kx[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0}, ky[9] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
+			const Homography dKdfocal(kf), dKdppx(kx), dKdppy(ky);
+
+			for (size_t pair_idx = 0; pair_idx < match_pairs.size(); ++pair_idx) {
+				const MatchPair& pair = match_pairs[pair_idx];
+				int idx = match_cnt_prefix_sum[pair_idx] * 2;
+				const int from = index_map[pair.from], to = index_map[pair.to];
+				const int param_idx_from = from * NR_PARAM_PER_CAMERA, param_idx_to = to * NR_PARAM_PER_CAMERA;
+				const auto& c_from = cameras[from]; const auto& c_to = cameras[to];
+				const auto fromK = c_from.K();
+				const auto toKinv = c_to.Kinv();
+				const auto toRinv = c_to.Rinv();
+				const auto& dRfromdvi = all_dRdvi[from];
+				auto dRtodviT = all_dRdvi[to];
+				for (auto& m : dRtodviT) m = m.transpose();
+				const Homography Hto_to_from = (fromK * c_from.R) * (toRinv * toKinv);
+
+				for (const auto& p : pair.m.match) {
+					const Vec2D to2 = p.first;
+					const Vec homo = Hto_to_from.trans(to2);
+					const double hz_sqr_inv = 1.0 / pano_sqr((float)homo.z);
+					const double hz_inv = 1.0 / homo.z;
+					// d(residual)/d(variable) = -d(point 2d)/d(homo 3d) * d(homo 3d)/d(variable)
+					auto drdv = [&](const Vec& dhdv) {
+						return Vec2D(-dhdv.x * hz_inv + dhdv.z * homo.x * hz_sqr_inv, -dhdv.y * hz_inv + dhdv.z * homo.y * hz_sqr_inv);
+					};
+					std::array<Vec2D, NR_PARAM_PER_CAMERA> dfrom, dto;
+					Homography m = c_from.R * toRinv * toKinv;
+					Vec dot_u2 = m.trans(to2);
+					dfrom[0] = drdv(dKdfocal.trans(dot_u2));
+					dfrom[1] = drdv(dKdppx.trans(dot_u2));
+					dfrom[2] = drdv(dKdppy.trans(dot_u2));
+					dot_u2 = (toRinv * toKinv).trans(to2);
+					dfrom[3] = drdv((fromK * dRfromdvi[0]).trans(dot_u2));
+					dfrom[4] = drdv((fromK * dRfromdvi[1]).trans(dot_u2));
+					dfrom[5] = drdv((fromK * dRfromdvi[2]).trans(dot_u2));
+					// d(Kinv)/dv = -Kinv dK/dv Kinv
+					m = fromK * c_from.R * toRinv * toKinv;
+					dot_u2 = toKinv.trans(to2) * (-1);
+					dto[0] = drdv((m * dKdfocal).trans(dot_u2));
+					dto[1] = drdv((m * dKdppx).trans(dot_u2));
+					dto[2] = drdv((m * dKdppy).trans(dot_u2));
+					m = fromK * c_from.R;
+					dot_u2 = toKinv.trans(to2);
+					dto[3] = drdv((m * dRtodviT[0]).trans(dot_u2));
+					dto[4] = drdv((m * dRtodviT[1]).trans(dot_u2));
+					dto[5] = drdv((m * dRtodviT[2]).trans(dot_u2));
+
+					// J^T r, the two rows of this match (J itself is never stored)
+					const double rx = residual[idx], ry = residual[idx + 1];
+					for (int i = 0; i < 6; ++i) {
+						Jtr[param_idx_from + i] += dfrom[i].x * rx; Jtr[param_idx_from + i] += dfrom[i].y * ry;
+						Jtr[param_idx_to + i] += dto[i].x * rx; Jtr[param_idx_to + i] += dto[i].y * ry;
+					}
+					// JtJ
+					for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+						const int i1 = param_idx_from + i, i2 = param_idx_to + j;
+						const double val = dfrom[i].dot(dto[j]);
+						JtJ[(size_t)i1 * np + i2] += val; JtJ[(size_t)i2 * np + i1] += val;
+					}
+					for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) {
+						int i1 = param_idx_from + i, i2 = param_idx_from + j;
+						double val = dfrom[i].dot(dfrom[j]);
+						JtJ[(size_t)i1 * np + i2] += val;
+						if (i != j) JtJ[(size_t)i2 * np + i1] += val;
+						i1 = param_idx_to + i; i2 = param_idx_to + j;
+						val = dto[i].dot(dto[j]);
+						JtJ[(size_t)i1 * np + i2] += val;
+						if (i != j) JtJ[(size_t)i2 * np + i1] += val;
+					}
+					idx += 2;
+				}
+			}
+		}
+};
+
+class CameraEstimator {
+	public:
+		CameraEstimator(std::vector<std::vector<MatchInfo>>& matches, const std::vector<Shape2D>& image_shapes):
+			n((int)matches.size()), matches(matches), shapes(image_shapes), cameras(matches.size()) {}
+		CameraEstimator(const CameraEstimator&) = delete;
+		CameraEstimator& operator=(const CameraEstimator&) = delete;
+
+		std::vector<Camera> estimate() {                        // camera_estimator.cc:47-103
+			estimate_focal();
+			IncrementalBundleAdjuster iba(cameras);
+			std::vector<bool> vst(n, false);
+			traverse(
+				[&](int node) {
+					cameras[node].R = Homography::I();
+					cameras[node].ppx = cameras[node].ppy = 0;
+					iba.set_identity_idx(node);
+				},
+				[&](int now, int next) {
+					const auto Kfrom = cameras[now].K();
+					const auto Kto = cameras[next].K();
+					const auto Hinv = matches[now][next].homo;          // from next to now
+					const auto Mat = Kfrom.inverse() * Hinv * Kto;
+					cameras[next].R = (cameras[now].Rinv() * Mat).transpose();
+					cameras[next].ppx = cameras[next].ppy = 0;
+					if (config::MULTIPASS_BA > 0) {
+						vst[now] = vst[next] = true;
+						for (int i = 0; i < n; ++i) if (vst[i] && i != next) {
+							const auto& m = matches[next][i];
+							if (m.match.size() && m.confidence > 0) {
+								iba.add_match(i, next, m);
+								if (config::MULTIPASS_BA == 2) iba.optimize();
+							}
+						}
+						if (config::MULTIPASS_BA == 1) iba.optimize();
+					}
+				});
+			if (config::MULTIPASS_BA == 0) {
+				for (int i = 1; i < n; ++i) for (int j = 0; j < i; ++j) {
+					auto& m = matches[j][i];
+					if (m.match.size() && m.confidence > 0) iba.add_match(i, j, m);
+				}
+				iba.optimize();
+			}
+			if (config::STRAIGHTEN) Camera::straighten(cameras);
+			return cameras;
+		}
+
+	protected:
+		int n;
+		std::vector<std::vector<MatchInfo>>& matches;
+		const std::vector<Shape2D>& shapes;
+		std::vector<Camera> cameras;
+
+		void estimate_focal() {                                  // :33-45
+			const double focal = Camera::estimate_focal(matches);
+			if (focal > 0) { for (auto& c : cameras) c.focal = focal; }
+			else for (int i = 0; i < n; ++i) cameras[i].focal = (shapes[i].w + shapes[i].h) * 0.5;
+		}
+
+		// maximum spanning tree by confidence, grown from the best edge (:105-158)
+		void traverse(std::function<void(int)> callback_init_node, std::function<void(int, int)> callback_edge) {
+			struct Edge {
+				int v1, v2; float weight;
+				Edge(int a, int b, float v): v1(a), v2(b), weight(v) {}
+				bool operator<(const Edge& r) const { return weight < r.weight; }
+			};
+			Edge best_edge{-1, -1, 0};
+			for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) {
+				auto& m = matches[i][j];
+				if (m.confidence > best_edge.weight) best_edge = Edge{i, j, m.confidence};
+			}
+			if (best_edge.v1 == -1) pano_error_exit("No connected images are found!");
+			callback_init_node(best_edge.v1);
+			std::priority_queue<Edge> q;
+			std::vector<bool> vst(n, false);
+			auto enqueue_edges_from = [&](int from) {
+				for (int i = 0; i < n; ++i) if (i != from && !vst[i]) {
+					auto& m = matches[from][i];
+					if (m.confidence > 0) q.emplace(from, i, m.confidence);
+				}
+			};
+			vst[best_edge.v1] = true;
+			enqueue_edges_from(best_edge.v1);
+			int cnt = 1;
+			while (q.size()) {
+				do { best_edge = q.top(); q.pop(); } while (q.size() && vst[best_edge.v2]);
+				if (vst[best_edge.v2]) break;
+				vst[best_edge.v2] = true;
+				cnt++;
+				callback_edge(best_edge.v1, best_edge.v2);
+				enqueue_edges_from(best_edge.v2);
+			}
+			if (cnt != n) {
+				std::string unconnected;
+				for (int i = 0; i < n; ++i) if (!vst[i]) unconnected += std::to_string(i) + " ";
+				pano_error_exit("Found a tree of size " + std::to_string(cnt) + "!=" + std::to_string(n) + ", image " + unconnected + "are not connected well!");
+			}
+		}
+};
+
+}	// namespace pano

@@ -14,6 +14,8 @@
 // file is not used.  Written from the interface description in SURVEY.md; no reference code.
 #pragma once
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <istream>
@@ -23,6 +25,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include "pano_la.hh"
 
 namespace config {
 inline bool CYLINDER = false, TRANS = false, CROP = true, ESTIMATE_CAMERA = true, STRAIGHTEN = true;
@@ -41,6 +44,8 @@ inline int RANSAC_ITERATIONS = 1500;
 inline double RANSAC_INLIER_THRES = (double)3.5f;
 inline float INLIER_IN_MATCH_RATIO = 0.1f, INLIER_IN_POINTS_RATIO = 0.04f;
 inline int MULTIBAND = 0;
+inline int MULTIPASS_BA = 1;
+inline float LM_LAMBDA = 5.f;
 }	// namespace config
 
 template <typename T>
@@ -51,12 +56,18 @@ struct Vector2D {
 	Vector2D operator+(const Vector2D& v) const { return Vector2D(x + v.x, y + v.y); }
 	Vector2D operator-(const Vector2D& v) const { return Vector2D(x - v.x, y - v.y); }
 	Vector2D operator*(T f) const { return Vector2D(x * f, y * f); }
+	T dot(const Vector2D& v) const { return x * v.x + y * v.y; }
 	bool isNaN() const { return std::isnan((double)x); }
 };
 template <typename T>
 struct Vector {
 	T x = 0, y = 0, z = 0;
 	explicit Vector(T mx = 0, T my = 0, T mz = 0): x(mx), y(my), z(mz) {}
+	// lib/geometry.hh:60-70
+	T sqr() const { return x * x + y * y + z * z; }
+	T dot(const Vector& v) const { return x * v.x + y * v.y + z * v.z; }
+	Vector cross(const Vector& v) const { return Vector(y * v.z - z * v.y, z * v.x - x * v.z, x * v.y - y * v.x); }
+	Vector operator*(T f) const { return Vector(x * f, y * f, z * f); }
 };
 typedef Vector<double> Vec;
 typedef Vector2D<int> Coor;
@@ -130,6 +141,32 @@ class Homography {
 			return Vec2D(r.x * denom, r.y * denom);
 		}
 		static Homography I() { Homography r; for (int i = 0; i < 9; ++i) r.data[i] = (i % 4 == 0); return r; }
+		Vec trans(const Vec2D& m) const { return trans(Vec(m.x, m.y, 1)); }
+		// stitch/homography.hh:36-50, homography.cc:25-48 (the product is a plain row-times-column sum
+		// from 0; the inverse is Eigen's FullPivLU in the reference, pano_la::inverse3 here)
+		Homography transpose() const {
+			const double t[9] = {data[0], data[3], data[6], data[1], data[4], data[7], data[2], data[5], data[8]};
+			return Homography(t);
+		}
+		Homography operator*(const Homography& r) const {
+			Homography ret;
+			for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+				double s = 0;
+				for (int k = 0; k < 3; ++k) s += data[i * 3 + k] * r.data[k * 3 + j];
+				ret.data[i * 3 + j] = s;
+			}
+			return ret;
+		}
+		void operator+=(const Homography& r) { for (int i = 0; i < 9; ++i) data[i] += r.data[i]; }
+		void mult(double r) { for (int i = 0; i < 9; ++i) data[i] *= r; }
+		Homography inverse(bool* succ = nullptr) const {
+			Homography ret;
+			const bool ok = pano_la::inverse3(data, ret.data);
+			if (succ) *succ = ok;
+			else if (!ok) { fprintf(stderr, "Homography::inverse: singular matrix\n"); abort(); }   // m_assert(lu.isInvertible())
+			return ret;
+		}
+		static Homography get_translation(double dx, double dy) { const double t[9] = {1, 0, dx, 0, 1, dy, 0, 0, 1}; return Homography(t); }
 		// text form of stitch/homography.hh:154-163 (default stream precision, like the reference)
 		void serialize(std::ostream& os) const { for (int i = 0; i < 8; ++i) os << data[i] << " "; os << data[8]; }
 		static Homography deserialize(std::istream& is) { Homography r; for (int i = 0; i < 9; ++i) is >> r[i]; return r; }

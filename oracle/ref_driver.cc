@@ -32,6 +32,10 @@
 #include "stitch/match_info.hh"
 #include "stitch/stitcher_image.hh"
 #include "stitch/warp.hh"
+#include "stitch/camera.hh"
+#include "stitch/camera_estimator.hh"
+#include "stitch/incremental_bundle_adjuster.hh"
+#include <Eigen/Dense>
 
 using namespace pano;
 using namespace config;
@@ -287,6 +291,96 @@ int ref_ransac(const int* match, int m, const double* kp1, int nk1, const double
 		}
 	}
 	return ok ? 1 : 0;
+}
+
+// CameraEstimator{pairwise_matches, shapes}.estimate() (stitch/camera_estimator.cc:31-103, the
+// body of Stitcher::estimate_camera, stitcher.cc:146-158) on a given pairwise MatchInfo table.
+// entries: np directed entries (i, j) -> pairwise_matches[i][j] = {conf, homo, pts}; pts rows are
+// (to.x, to.y, from.x, from.y).  out: per image focal, aspect, ppx, ppy, R[9] (13 doubles).
+// Also exposes the helpers for unit checks.
+int ref_estimate_cameras(int n, const int* shapes_wh, int np, const int* ij, const float* conf, const double* homo,
+		const int* cnt, const double* pts, double* out) {
+	std::vector<std::vector<MatchInfo>> pm(n, std::vector<MatchInfo>(n));
+	size_t at = 0;
+	for (int e = 0; e < np; ++e) {
+		MatchInfo& m = pm[ij[2 * e]][ij[2 * e + 1]];
+		m.confidence = conf[e];
+		for (int k = 0; k < 9; ++k) m.homo[k] = homo[9 * e + k];
+		for (int k = 0; k < cnt[e]; ++k, ++at)
+			m.match.emplace_back(Vec2D(pts[4 * at], pts[4 * at + 1]), Vec2D(pts[4 * at + 2], pts[4 * at + 3]));
+	}
+	std::vector<Shape2D> shapes;
+	for (int i = 0; i < n; ++i) shapes.emplace_back(shapes_wh[2 * i], shapes_wh[2 * i + 1]);
+	std::vector<Camera> cams = CameraEstimator{pm, shapes}.estimate();
+	for (int i = 0; i < n; ++i) {
+		double* o = out + 13 * i;
+		o[0] = cams[i].focal; o[1] = cams[i].aspect; o[2] = cams[i].ppx; o[3] = cams[i].ppy;
+		for (int k = 0; k < 9; ++k) o[4 + k] = cams[i].R[k];
+	}
+	return 0;
+}
+// One Levenberg-Marquardt step of the bundle adjuster on given cameras, with its internals
+// exposed: residuals (calcError), damped JtJ and the parameter update (get_param_update) --
+// IncrementalBundleAdjuster's protected members reached through a subclass.
+struct IbaProbe : public IncrementalBundleAdjuster {
+	using IncrementalBundleAdjuster::IncrementalBundleAdjuster;
+	void probe(int identity, double* resid, double* jtj, double* upd) {
+		set_identity_idx(identity);
+		update_index_map();
+		int nr_img = idx_added.size();
+		J = Eigen::MatrixXd{2 * nr_pointwise_match, 6 * nr_img};
+		JtJ = Eigen::MatrixXd{6 * nr_img, 6 * nr_img};
+		ParamState state;
+		for (auto& idx : idx_added) state.cameras.emplace_back(result_cameras[idx]);
+		state.ensure_params();
+		state.cameras.clear();
+		auto err = calcError(state);
+		for (size_t i = 0; i < err.residuals.size(); ++i) resid[i] = err.residuals[i];
+		Eigen::VectorXd u = get_param_update(state, err.residuals, LM_LAMBDA);
+		for (int i = 0; i < 36 * nr_img * nr_img; ++i) jtj[i] = JtJ.p[i];
+		for (int i = 0; i < 6 * nr_img; ++i) upd[i] = u(i);
+	}
+};
+int ref_iba_probe(int n, const double* cams, int np, const int* ij, const int* cnt, const double* pts, int identity,
+		double* resid, double* jtj, double* upd) {
+	std::vector<Camera> cameras(n);
+	for (int i = 0; i < n; ++i) {
+		const double* o = cams + 13 * i;
+		cameras[i].focal = o[0]; cameras[i].aspect = o[1]; cameras[i].ppx = o[2]; cameras[i].ppy = o[3];
+		for (int k = 0; k < 9; ++k) cameras[i].R[k] = o[4 + k];
+	}
+	std::vector<MatchInfo> infos(np);
+	size_t at = 0;
+	for (int e = 0; e < np; ++e)
+		for (int k = 0; k < cnt[e]; ++k, ++at)
+			infos[e].match.emplace_back(Vec2D(pts[4 * at], pts[4 * at + 1]), Vec2D(pts[4 * at + 2], pts[4 * at + 3]));
+	IbaProbe iba(cameras);
+	for (int e = 0; e < np; ++e) iba.add_match(ij[2 * e], ij[2 * e + 1], infos[e]);
+	iba.probe(identity, resid, jtj, upd);
+	return 0;
+}
+void ref_rotation_to_angle(const double* r, double* v) {
+	Homography h; for (int k = 0; k < 9; ++k) h[k] = r[k];
+	Camera::rotation_to_angle(h, v[0], v[1], v[2]);
+}
+void ref_angle_to_rotation(const double* v, double* r) {
+	Homography h; Camera::angle_to_rotation(v[0], v[1], v[2], h);
+	for (int k = 0; k < 9; ++k) r[k] = h[k];
+}
+int ref_homography_inverse(const double* a, double* inv) {
+	Homography h; for (int k = 0; k < 9; ++k) h[k] = a[k];
+	bool ok = false;
+	Homography r = h.inverse(&ok);
+	if (ok) for (int k = 0; k < 9; ++k) inv[k] = r[k];
+	return ok ? 1 : 0;
+}
+// solve through the stand-in ColPivHouseholderQR (what IBA::get_param_update calls)
+void ref_colpiv_solve(const double* A, int n, const double* b, double* x) {
+	Eigen::MatrixXd M(n, n); Eigen::VectorXd B(n);
+	for (int i = 0; i < n * n; ++i) M.p[i] = A[i];
+	for (int i = 0; i < n; ++i) B(i) = b[i];
+	Eigen::VectorXd X = M.colPivHouseholderQr().solve(B).eval();
+	for (int i = 0; i < n; ++i) x[i] = X(i);
 }
 
 float ref_euclidean_sqr(const float* x, const float* y, int n, float thres) {

@@ -1,0 +1,122 @@
+"""CPU: the Eigen-free host camera estimation / bundle adjustment (openpano_amd/host/pano_camera.hh,
+pano_la.hh) against the reference's own Camera / CameraEstimator /
+IncrementalBundleAdjuster compiled in place (oracle/_ref; its Eigen calls go to the stand-in of
+oracle/ref_shim).  Both sides run the same published LA algorithms and the same
+operation order, so the comparison is bit-for-bit; physical sanity (focal, reprojection error)
+is checked against the synthetic ground truth on top."""
+import numpy as np
+import pytest
+
+from camera_util import host_impl, ref_impl, reprojection_rms, rot, rotating_camera_scene
+
+
+@pytest.fixture(scope="module")
+def host():
+    return host_impl()
+
+
+@pytest.fixture(scope="module")
+def refc(ref):
+    return ref_impl(ref)
+
+
+def test_rotation_maps_equal_reference_and_round_trip(host, refc):
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        v = rng.normal(0, 1.0, 3) * (1e-9 if k % 17 == 0 else 1.0)       # incl. the first-order branch (theta^2 < 1e-14)
+        R = host.angle_to_rotation(v)
+        assert np.array_equal(R, refc.angle_to_rotation(v))
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) or k % 17 == 0
+        Rn = R + rng.normal(0, 1e-3, (3, 3))                              # not exactly a rotation: goes through the SVD projection
+        a, b = host.rotation_to_angle(Rn), refc.rotation_to_angle(Rn)
+        assert np.array_equal(a, b)
+        if k % 17:
+            assert np.allclose(host.rotation_to_angle(R), v if np.linalg.norm(v) < np.pi else host.rotation_to_angle(R), atol=1e-9)
+
+
+def test_inverse_and_qr_solve_equal_reference(host, refc):
+    rng = np.random.default_rng(6)
+    for _ in range(50):
+        A = rng.normal(0, 1, (3, 3)) * np.array([1.0, 1.0, 1e-3])
+        ok1, i1 = host.inverse(A); ok2, i2 = refc.inverse(A)
+        assert ok1 == ok2 and np.array_equal(i1, i2) and np.allclose(i1 @ A, np.eye(3), atol=1e-8)
+    ok1, _ = host.inverse(np.array([[1.0, 2, 3], [2, 4, 6], [1, 0, 1]])); ok2, _ = refc.inverse(np.array([[1.0, 2, 3], [2, 4, 6], [1, 0, 1]]))
+    assert ok1 is False and ok2 is False
+    for n in (6, 12, 42, 120):
+        J = rng.normal(0, 1, (3 * n, n)); A = J.T @ J + np.diag(np.where(np.arange(n) % 6 >= 3, 5.0, 0.5)); b = rng.normal(0, 1, n)
+        x1, x2 = host.solve(A, b), refc.solve(A, b)
+        assert np.array_equal(x1, x2)
+        assert np.allclose(A @ x1, b, atol=1e-8 * np.abs(b).max() * n)
+    # rank-deficient system: both give the same basic solution
+    A = np.zeros((6, 6)); A[:3, :3] = np.array([[4.0, 1, 0], [1, 3, 1], [0, 1, 2]]); b = np.array([1.0, 2, 3, 0, 0, 0])
+    assert np.array_equal(host.solve(A, b), refc.solve(A, b))
+
+
+def test_lm_step_internals_equal_reference(host, refc):
+    """Residuals, damped JtJ and the parameter update of one LM step on cameras that are NOT at the
+    optimum (large residuals, every derivative term live).  Also pins the reference's fp32 sqr()
+    (lib/utils.hh:25) inside 1/z^2: replacing it by a double square changes JtJ in the 9th digit."""
+    shapes, table, (focal, Rs) = rotating_camera_scene(4, n=4)
+    cams = np.zeros((4, 13))
+    for k in range(4):
+        cams[k] = [focal * (1.0 + 0.01 * k), 1.0, 0.3 * k, -0.2 * k, *(rot(0.02 * k, -0.01, 0.005) @ Rs[k]).reshape(9)]
+    entries = [(e[0], e[1], e[4]) for e in table if e[0] < e[1]]
+    for lam in (5.0, 0.5, 0.03):
+        host.config(LM_LAMBDA=lam); refc.config(LM_LAMBDA=lam)
+        try:
+            a = host.lm_step(cams, entries, 1); b = refc.lm_step(cams, entries, 1)
+        finally:
+            host.config(LM_LAMBDA=5.0); refc.config(LM_LAMBDA=5.0)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert np.allclose(a[1], a[1].T) and np.abs(a[0]).max() > 1.0
+    # numerical cross-check of the analytic derivative: J^T r from central differences of the residuals
+    res0, jtj, upd = host.lm_step(cams, entries, 1)
+    lam = 5.0
+    g = jtj @ upd                                     # (JtJ + D) x = J^T r  ->  J^T r
+    eps = 1e-6
+    for p in (0, 1, 3, 4, 8, 10):                     # a few parameters: focal / ppx / rotation of cameras 0 and 1
+        k, q = divmod(p, 6)
+        def residual_with(delta):
+            c = cams.copy()
+            if q == 0: c[k, 0] += delta
+            elif q == 1: c[k, 2] += delta
+            elif q == 2: c[k, 3] += delta
+            else:
+                v = host.rotation_to_angle(c[k, 4:].reshape(3, 3)); v[q - 3] += delta
+                c[k, 4:] = host.angle_to_rotation(v).reshape(9)
+            return host.lm_step(c, entries, 1)[0]
+        dr = (residual_with(eps) - residual_with(-eps)) / (2 * eps)
+        assert abs(dr @ res0 - g[p]) <= 2e-4 * max(1.0, abs(g[p])), (p, dr @ res0, g[p])
+
+
+@pytest.mark.parametrize("mode", [dict(MULTIPASS_BA=1, STRAIGHTEN=1), dict(MULTIPASS_BA=0, STRAIGHTEN=1),
+                                  dict(MULTIPASS_BA=2, STRAIGHTEN=0), dict(MULTIPASS_BA=1, STRAIGHTEN=0, LM_LAMBDA=0.5)])
+@pytest.mark.parametrize("scene", [dict(seed=1, n=7, rows=1), dict(seed=2, n=10, rows=2, step_deg=11.0), dict(seed=3, n=4, rows=1, noise=1.0)])
+def test_estimate_cameras_equal_reference(host, refc, mode, scene):
+    full = dict(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0); full.update(mode)
+    shapes, table, (focal, Rs) = rotating_camera_scene(**scene)
+    host.config(**full); refc.config(**full)
+    try:
+        mine = host.estimate(shapes, table)
+        theirs = refc.estimate(shapes, table)
+    finally:
+        host.config(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0); refc.config(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0)
+    assert np.array_equal(mine, theirs)
+    # and the estimate is a good one: focal within 3 %, sub-pixel-level reprojection error
+    assert np.all(np.abs(mine[:, 0] / focal - 1) < 0.03), mine[:, 0]
+    assert reprojection_rms(mine, table) < 2.5 * scene.get("noise", 0.4) + 0.2
+    for k in range(len(shapes)):
+        R = mine[k, 4:].reshape(3, 3)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-9)
+
+
+def test_unconnected_image_is_an_error(host):
+    """error_exit("Found a tree of size ...") (camera_estimator.cc:150-157): the process ends with
+    status 1 and the reference's message -- checked in a child process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from camera_util import host_impl, rotating_camera_scene;"
+            "s, t, _ = rotating_camera_scene(1, n=5); t = [e for e in t if 4 not in (e[0], e[1])]; host_impl().estimate(s, t)") % __import__("os").path.dirname(__file__)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "Found a tree of size 4!=5" in p.stderr and "not connected well" in p.stderr
