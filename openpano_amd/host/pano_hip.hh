@@ -45,6 +45,7 @@
 #include "stitch/stitcher_image.hh"
 #else
 #include "pano_types.hh"
+#include "pano_camera.hh"
 #endif
 
 namespace pano {
@@ -129,6 +130,7 @@ struct HipFeatureSet {
 	HipFeatureSet(const HipFeatureSet&) = delete;
 	HipFeatureSet& operator=(const HipFeatureSet&) = delete;
 	HipFeatureSet(HipFeatureSet&& o): handle(o.handle), feats(std::move(o.feats)) { o.handle = nullptr; }
+	HipFeatureSet& operator=(HipFeatureSet&& o) { if (this != &o) { op_features_free(handle); handle = o.handle; feats = std::move(o.feats); o.handle = nullptr; } return *this; }
 	~HipFeatureSet() { op_features_free(handle); }
 };
 
@@ -395,13 +397,16 @@ struct ConnectedImages {
 		ImageComponent(ImageRef* img): imgptr(img) {}
 	};
 	std::vector<ImageComponent> component;
-	void calc_inverse_homo() { prepare(); }
-	void update_proj_range() { prepare(); }
+	// stitcher_image.cc:36-77: homo_inv from homo; ranges / proj_range / resolution from homo.  Kept
+	// separate like the reference's: Stitcher::estimate_camera sets homo_inv = K R itself and only
+	// calls update_proj_range() (stitcher.cc:154-158, :59)
+	void calc_inverse_homo() { prepare(true, false); }
+	void update_proj_range() { prepare(false, true); }
 	Vec2D get_final_resolution() const { return resolution; }
 	Mat32f blend() const;
 	Vec2D resolution;
 	private:
-	void prepare();       // calc_inverse_homo + update_proj_range + get_final_resolution in one host call
+	void prepare(bool set_inverse, bool set_range);       // one host call of the C-ABI's geometry helper
 };
 #endif
 
@@ -464,15 +469,17 @@ inline Mat32f hip_blend(const Bundle& b, bool crop = false) {
 }
 
 #ifndef OPENPANO_WITH_REFERENCE
-inline void ConnectedImages::prepare() {
+inline void ConnectedImages::prepare(bool set_inverse, bool set_range) {
 	std::vector<double> hinv, ranges;
 	const op_blend_geom g = hip_blend_prepare(*this, hinv, ranges);
 	for (size_t i = 0; i < component.size(); ++i) {
-		for (int k = 0; k < 9; ++k) component[i].homo_inv[k] = hinv[i * 9 + k];
-		component[i].range = Range(Vec2D(ranges[4 * i], ranges[4 * i + 1]), Vec2D(ranges[4 * i + 2], ranges[4 * i + 3]));
+		if (set_inverse) for (int k = 0; k < 9; ++k) component[i].homo_inv[k] = hinv[i * 9 + k];
+		if (set_range) component[i].range = Range(Vec2D(ranges[4 * i], ranges[4 * i + 1]), Vec2D(ranges[4 * i + 2], ranges[4 * i + 3]));
 	}
-	proj_range = Range(Vec2D(g.proj_min[0], g.proj_min[1]), Vec2D(g.proj_max[0], g.proj_max[1]));
-	resolution = Vec2D(g.resolution[0], g.resolution[1]);
+	if (set_range) {
+		proj_range = Range(Vec2D(g.proj_min[0], g.proj_min[1]), Vec2D(g.proj_max[0], g.proj_max[1]));
+		resolution = Vec2D(g.resolution[0], g.resolution[1]);
+	}
 }
 inline Mat32f ConnectedImages::blend() const { return hip_blend(*this); }
 #endif
@@ -514,7 +521,127 @@ class HipCylinderWarper {
 };
 
 #ifndef OPENPANO_WITH_REFERENCE
+// ===================================== STITCHER =====================================
+// Stitcher (stitch/stitcher.hh:17-62, stitcher.cc:32-198) + StitcherBase (stitcherbase.hh:17-64),
+// standalone: the whole of Stitcher::build() with the device stages batched -- one SIFT call for
+// all images, one match call and one RANSAC call for the whole pair list -- and the host stages
+// (camera estimation / bundle adjustment, pano_camera.hh) in between.  Members keep the
+// reference's names; `cameras` and `base_seed` (RANSAC seed injection) are additions.
+class HipStitcher {
+	public:
+		explicit HipStitcher(const std::vector<Mat32f>& mats, uint32_t base_seed = 42u): base_seed(base_seed) {
+			if (mats.size() <= 1) { fprintf(stderr, "Cannot stitch with only %zu images.\n", mats.size()); exit(1); }   // stitcherbase.hh:46-48
+			for (auto& m : mats) imgs.emplace_back(m);
+			for (auto& r : imgs) bundle.component.emplace_back(&r);
+		}
+		HipStitcher(const HipStitcher&) = delete;
+		HipStitcher& operator=(const HipStitcher&) = delete;
+
+		Mat32f build() {                                            // stitcher.cc:32-64
+			calc_feature();
+			pairwise_matches.assign(imgs.size(), std::vector<MatchInfo>(imgs.size()));
+			if (config::ORDERED_INPUT) linear_pairwise_match();
+			else pairwise_match();
+			assign_center();
+			if (config::ESTIMATE_CAMERA) estimate_camera();
+			else build_linear_simple();
+			bundle.proj_method = config::ESTIMATE_CAMERA ? ConnectedImages::spherical : ConnectedImages::flat;
+			bundle.update_proj_range();
+			return bundle.blend();
+		}
+
+		std::vector<ImageRef> imgs;
+		HipFeatureSet feats;                                        // StitcherBase::feats + the resident device copy
+		std::vector<std::vector<Vec2D>> keypoints;
+		std::vector<std::vector<MatchInfo>> pairwise_matches;
+		ConnectedImages bundle;
+		std::vector<Camera> cameras;
+		uint32_t base_seed;
+
+		void calc_feature() {                                       // stitcherbase.cc:9-27
+			std::vector<const Mat32f*> ptrs;
+			for (auto& r : imgs) ptrs.push_back(r.img);
+			feats = HipSIFTDetector().calc_feature(ptrs);
+			keypoints.resize(imgs.size());
+			for (size_t k = 0; k < imgs.size(); ++k) {
+				keypoints[k].clear();
+				for (auto& d : feats.feats[k]) keypoints[k].emplace_back(d.coor);
+			}
+		}
+		void pairwise_match() {                                     // stitcher.cc:96-113
+			std::vector<std::pair<int, int>> tasks;
+			for (int i = 0; i < (int)imgs.size(); ++i) for (int j = i + 1; j < (int)imgs.size(); ++j) tasks.emplace_back(i, j);
+			match_tasks(tasks, false);
+		}
+		void linear_pairwise_match() {                              // stitcher.cc:115-136
+			const int n = (int)imgs.size();
+			std::vector<std::pair<int, int>> tasks;
+			for (int i = 0; i < n; ++i) tasks.emplace_back(i, (i + 1) % n);
+			match_tasks(tasks, true);
+		}
+		void assign_center() { bundle.identity_idx = (int)imgs.size() >> 1; }   // stitcher.cc:138-141
+		void estimate_camera() {                                    // stitcher.cc:143-158
+			std::vector<Shape2D> shapes;
+			for (auto& m : imgs) shapes.emplace_back(m.shape());
+			cameras = CameraEstimator{pairwise_matches, shapes}.estimate();
+			for (size_t i = 0; i < imgs.size(); ++i) {
+				bundle.component[i].homo_inv = cameras[i].K() * cameras[i].R;
+				bundle.component[i].homo = cameras[i].Rinv() * cameras[i].K().inverse();
+			}
+		}
+		void build_linear_simple() {                                // stitcher.cc:160-198
+			const int n = (int)imgs.size(), mid = bundle.identity_idx;
+			auto& comp = bundle.component;
+			comp[mid].homo = Homography::I();
+			if (mid + 1 < n) {
+				comp[mid + 1].homo = pairwise_matches[mid][mid + 1].homo;
+				for (int k = mid + 2; k < n; ++k) comp[k].homo = comp[k - 1].homo * pairwise_matches[k - 1][k].homo;
+			}
+			if (mid - 1 >= 0) {
+				comp[mid - 1].homo = pairwise_matches[mid][mid - 1].homo;
+				for (int k = mid - 2; k >= 0; --k) comp[k].homo = comp[k + 1].homo * pairwise_matches[k + 1][k].homo;
+			}
+			double f = -1;
+			if (!config::TRANS) f = Camera::estimate_focal(pairwise_matches);
+			if (f <= 0) f = 0.5 * (imgs[mid].width() + imgs[mid].height());
+			for (int i = 0; i < n; ++i) {
+				const double t[9] = {1.0 / f, 0, 0, 0, 1.0 / f, 0, 0, 0, 1};
+				comp[i].homo = Homography(t) * comp[i].homo;
+			}
+			bundle.calc_inverse_homo();
+		}
+
+		// match_image (stitcher.cc:66-94) for a whole task list: one match call + one RANSAC call,
+		// then the reference's bookkeeping per connected pair
+		void match_tasks(const std::vector<std::pair<int, int>>& tasks, bool linear) {
+			std::vector<Shape2D> shapes;
+			for (auto& r : imgs) shapes.push_back(r.shape());
+			record_matches(tasks, hip_match_images(feats, shapes, tasks, base_seed), linear);
+		}
+		void record_matches(const std::vector<std::pair<int, int>>& tasks, const std::vector<std::pair<bool, MatchInfo>>& infos, bool linear) {
+			const int n = (int)imgs.size();
+			for (size_t k = 0; k < tasks.size(); ++k) {
+				const int i = tasks[k].first, j = tasks[k].second;
+				if (!infos[k].first) {
+					if (linear && i != n - 1) {       // head and tail don't have to match (stitcher.cc:123-127)
+						fprintf(stderr, "error: Image %d and %d don't match\n", i, j);
+						exit(1);
+					}
+					continue;
+				}
+				MatchInfo info = infos[k].second;
+				Homography inv = info.homo.inverse();       // TransformEstimation ensures invertible
+				inv.mult(1.0 / inv[8]);
+				pairwise_matches[i][j] = info;
+				info.homo = inv;
+				info.reverse();
+				pairwise_matches[j][i] = std::move(info);
+			}
+		}
+};
+
 // standalone builds read like the reference
+using Stitcher = HipStitcher;
 using SIFTDetector = HipSIFTDetector;
 using PairWiseMatcher = HipPairWiseMatcher;
 using TransformEstimation = HipTransformEstimation;

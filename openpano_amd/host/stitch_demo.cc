@@ -4,7 +4,11 @@
 //   replaced here by chaining the pairwise homographies to the middle image] -> blend,
 // written with the reference's class and method names.
 //
-//   stitch_demo <in.bin> <out.bin> [base_seed]
+//   stitch_demo <in.bin> <out.bin> [base_seed] [camera]
+// With "camera" the program runs the ESTIMATE_CAMERA branch of Stitcher::build() instead (BASELINE
+// configs 2-4): all pairs matched, homography RANSAC, host camera estimation + bundle adjustment
+// (pano_camera.hh), spherical blend; out.bin then carries n*13 f64 cameras (focal, aspect, ppx,
+// ppy, R) in place of the chain homographies, before the canvas.
 // in.bin : int32 n, h, w ; n*h*w*3 float32 (Mat32f layout)
 // out.bin: per image   int32 K ; K*128 f32 ; K*2 f64
 //          int32 npairs ; per pair int32 i, j, M ; M*2 int32 ; int32 ok ; f32 confidence ; 9 f64 ; int32 ninl ; ninl*4 f64
@@ -13,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "pano_hip.hh"
@@ -33,6 +38,69 @@ static Homography mul(const Homography& a, const Homography& b) {
 	return r;
 }
 
+static void put_features(FILE* fo, const HipFeatureSet& fs) {
+	for (size_t k = 0; k < fs.feats.size(); ++k) {
+		put1<int32_t>(fo, (int32_t)fs.feats[k].size());
+		for (auto& d : fs.feats[k]) put(fo, d.descriptor.data(), 128);
+		for (auto& d : fs.feats[k]) { double c[2] = {d.coor.x, d.coor.y}; put(fo, c, 2); }
+		fprintf(stderr, "Image %zu has %zu features\n", k, fs.feats[k].size());
+	}
+}
+static void put_pairs(FILE* fo, const HipFeatureSet& fs, const std::vector<std::pair<int, int>>& tasks,
+		const std::vector<std::pair<bool, MatchInfo>>& infos) {
+	PairWiseMatcher pwmatcher(fs);
+	pwmatcher.precompute(tasks);
+	put1<int32_t>(fo, (int32_t)tasks.size());
+	for (size_t p = 0; p < tasks.size(); ++p) {
+		MatchData md = pwmatcher.match(tasks[p].first, tasks[p].second);
+		put1<int32_t>(fo, tasks[p].first); put1<int32_t>(fo, tasks[p].second); put1<int32_t>(fo, md.size());
+		for (auto& q : md.data) { int32_t v[2] = {q.first, q.second}; put(fo, v, 2); }
+		const MatchInfo& info = infos[p].second;
+		put1<int32_t>(fo, infos[p].first ? 1 : 0); put1<float>(fo, info.confidence);
+		double hh[9]; for (int i = 0; i < 9; ++i) hh[i] = infos[p].first ? info.homo[i] : 0.0;
+		put(fo, hh, 9);
+		put1<int32_t>(fo, (int32_t)(infos[p].first ? info.match.size() : 0));
+		if (infos[p].first) for (auto& m : info.match) { double v[4] = {m.first.x, m.first.y, m.second.x, m.second.y}; put(fo, v, 4); }
+		fprintf(stderr, "pair (%d,%d): %d matches, %s, confidence %g\n", tasks[p].first, tasks[p].second, md.size(),
+				infos[p].first ? "connected" : "rejected", info.confidence);
+	}
+}
+
+// Stitcher::build() under ESTIMATE_CAMERA (stitch/stitcher.cc:32-64), stage by stage so that every
+// intermediate can be written out
+static int run_camera_mode(const std::vector<Mat32f>& mats, const char* out_path, uint32_t base_seed) {
+	Stitcher st(mats, base_seed);
+	FILE* fo = fopen(out_path, "wb");
+	if (!fo) { perror(out_path); return 2; }
+	st.calc_feature();
+	put_features(fo, st.feats);
+	const int n = (int)mats.size();
+	st.pairwise_matches.assign(n, std::vector<MatchInfo>(n));
+	std::vector<std::pair<int, int>> tasks;
+	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) tasks.emplace_back(i, j);
+	std::vector<Shape2D> shapes;
+	for (auto& r : st.imgs) shapes.push_back(r.shape());
+	auto infos = hip_match_images(st.feats, shapes, tasks, base_seed);
+	put_pairs(fo, st.feats, tasks, infos);
+	st.record_matches(tasks, infos, false);
+	st.assign_center();
+	st.estimate_camera();
+	for (auto& c : st.cameras) {
+		double v[13] = {c.focal, c.aspect, c.ppx, c.ppy};
+		for (int k = 0; k < 9; ++k) v[4 + k] = c.R[k];
+		put(fo, v, 13);
+		fprintf(stderr, "camera focal=%g ppx=%g ppy=%g\n", c.focal, c.ppx, c.ppy);
+	}
+	st.bundle.proj_method = ConnectedImages::spherical;
+	st.bundle.update_proj_range();
+	Mat32f pano = st.bundle.blend();
+	put1<int32_t>(fo, pano.rows()); put1<int32_t>(fo, pano.cols());
+	put(fo, pano.ptr(), (size_t)pano.rows() * pano.cols() * 3);
+	fprintf(stderr, "Final Image Size: (%d, %d)\n", pano.cols(), pano.rows());
+	fclose(fo);
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin [base_seed]\n", argv[0]); return 2; }
 	const uint32_t base_seed = argc > 3 ? (uint32_t)strtoul(argv[3], nullptr, 10) : 42u;
@@ -47,8 +115,10 @@ int main(int argc, char** argv) {
 		if (fread(mats.back().ptr(), sizeof(float), (size_t)h * w * 3, fi) != (size_t)h * w * 3) return 2;
 	}
 	fclose(fi);
-	config::ORDERED_INPUT = true; config::ESTIMATE_CAMERA = false; config::TRANS = true;   // TRANS mode: affine RANSAC, flat blend
+	const bool camera_mode = argc > 4 && std::string(argv[4]) == "camera";
+	config::ORDERED_INPUT = !camera_mode; config::ESTIMATE_CAMERA = camera_mode; config::TRANS = !camera_mode;   // TRANS mode: affine RANSAC, flat blend
 	config::LAZY_READ = false;
+	if (camera_mode) return run_camera_mode(mats, argv[2], base_seed);
 
 	// ---- StitcherBase::calc_feature (stitch/stitcherbase.cc:9-27)
 	std::vector<ImageRef> imgs;

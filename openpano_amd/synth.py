@@ -151,3 +151,40 @@ def pano_scene(n: int, h: int, w: int, seed: int, proj: str = "flat", focal: flo
             H = Ry @ Rx @ Rz @ np.diag([1.0 / f, 1.0 / f, 1.0])
         homos.append(H)
     return views, np.stack(homos)
+
+
+def rotating_views(n: int, h: int, w: int, seed: int, focal: float = None, step_deg: float = 20.0, rows: int = 1):
+    """``n`` h x w views of a camera ROTATING about its centre (the ESTIMATE_CAMERA model: pixel
+    = K R ray, stitch/camera.hh), rendered from one equirectangular world texture, so that any two
+    overlapping views are related by the exact homography K R_a R_b^T K^-1.  Pixel coordinates are
+    centred ((c + 0.5 - w/2, r + 0.5 - h/2), like the keypoints of FeatureDetector::detect_feature).
+    Returns (views, focal, [R_i])."""
+    rng = np.random.default_rng(seed)
+    f = float(focal or 0.95 * w)
+    cols = -(-n // rows)
+    Rs = []
+    for k in range(n):
+        r, c = divmod(k, cols)
+        yaw = np.deg2rad((c - (cols - 1) / 2) * step_deg + rng.uniform(-1.0, 1.0))
+        pitch = np.deg2rad((r - (rows - 1) / 2) * 0.55 * np.rad2deg(2 * np.arctan(h / 2 / f)) + rng.uniform(-1.0, 1.0))
+        roll = np.deg2rad(rng.uniform(-1.5, 1.5))
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        Rs.append(Rz @ Rx @ Ry)
+    half_x = np.deg2rad((cols - 1) / 2 * step_deg + 4) + np.arctan(np.hypot(w, h) / 2 / f)
+    half_y = np.deg2rad(4) + (rows - 1) / 2 * 0.55 * 2 * np.arctan(h / 2 / f) + np.arctan(np.hypot(w, h) / 2 / f)
+    Hw, Ww = int(2 * half_y * f) + 8, int(2 * half_x * f) + 8
+    world = make_world(seed, Hw, Ww, work_scale=1600.0 / (h + w), density=500.0)
+    u = np.arange(w) + 0.5 - w / 2; v = np.arange(h) + 0.5 - h / 2
+    uu, vv = np.meshgrid(u, v)
+    rays = np.stack([uu / f, vv / f, np.ones_like(uu)], -1)
+    views = []
+    for R in Rs:
+        X = rays @ R                                   # R^T ray, row-vector form
+        theta = np.arctan2(X[..., 0], X[..., 2]); phi = np.arctan2(X[..., 1], np.hypot(X[..., 0], X[..., 2]))
+        xs = (theta + half_x) * f; ys = (phi + half_y) * f
+        xs = np.clip(xs, 0, Ww - 1.001); ys = np.clip(ys, 0, Hw - 1.001)
+        views.append(np.ascontiguousarray(_bilinear_sample(world, ys, xs).astype(np.float32)))
+    return views, f, Rs

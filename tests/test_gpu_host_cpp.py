@@ -96,6 +96,78 @@ def test_stitch_demo(tmp_path, oracle, n, h, w, seed):
     assert np.array_equal(pano, want)          # flat projection: no transcendental -> bit-exact
 
 
+def test_stitch_demo_estimate_camera(tmp_path, oracle):
+    """The ESTIMATE_CAMERA branch of Stitcher::build() end to end in the standalone C++ program
+    (device SIFT / match / RANSAC, host camera estimation + bundle adjustment, device spherical
+    blend): features, matches and RANSAC results against the CPU oracle, the cameras against the
+    reference's own CameraEstimator (oracle/_ref, when built) on the SAME pairwise table, the
+    panorama against the oracle's blend under those cameras."""
+    assert os.path.exists(DEMO), "build it: make -C openpano_amd/csrc"
+    n, h, w = 5, 300, 400
+    views, focal, Rs = synth.rotating_views(n, h, w, seed=77, step_deg=22.0)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<3i", n, h, w))
+        for v in views:
+            f.write(np.ascontiguousarray(v, np.float32).tobytes())
+    base_seed = 42
+    r = subprocess.run([DEMO, str(fin), str(fout), str(base_seed), "camera"], capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rd = _Reader(open(fout, "rb").read())
+    cfg = PanoConfig(ESTIMATE_CAMERA=1, TRANS=0, ORDERED_INPUT=0, LAZY_READ=0)
+    from checkers import Oracle, ref_available, Ref
+    from camera_util import host_impl, ref_impl, reprojection_rms
+    orc = Oracle(cfg)
+    descs, coors = [], []
+    for k in range(n):
+        K = int(rd.take(np.int32, 1)[0])
+        d = rd.take(np.float32, K * 128).reshape(K, 128); c = rd.take(np.float64, K * 2).reshape(K, 2)
+        od, oc = orc.detect_feature(views[k])
+        assert K > 100 and np.array_equal(d, od) and np.array_equal(c, oc), f"image {k}"
+        descs.append(d); coors.append(c)
+    npairs = int(rd.take(np.int32, 1)[0])
+    assert npairs == n * (n - 1) // 2
+    host = host_impl()
+    table = []
+    for p in range(npairs):
+        i, j, M = (int(x) for x in rd.take(np.int32, 3))
+        m = rd.take(np.int32, M * 2).reshape(M, 2)
+        assert np.array_equal(m, orc.match_exact(descs[i], descs[j])), f"pair {p}"
+        ok = int(rd.take(np.int32, 1)[0]); conf = float(rd.take(np.float32, 1)[0])
+        homo = rd.take(np.float64, 9).reshape(3, 3); ninl = int(rd.take(np.int32, 1)[0])
+        pts = rd.take(np.float64, ninl * 4).reshape(ninl, 4)
+        seed = ((base_seed * 2654435761) ^ (p * 40503 + 12345)) & 0xFFFFFFFF
+        o = orc.ransac(m, coors[i], coors[j], (w, h), (w, h), seed, cfg)
+        assert bool(ok) == o["ok"] and conf == np.float32(o["confidence"]), f"pair {p}"
+        if ok:
+            inl = o["inliers"]
+            assert np.array_equal(pts[:, :2], coors[i][m[inl, 0]]) and np.array_equal(pts[:, 2:], coors[j][m[inl, 1]])
+            assert np.allclose(homo, o["homo"], rtol=1e-9, atol=1e-12)
+            good, inv = host.inverse(homo); assert good
+            inv = inv * (1.0 / inv[2, 2])
+            table.append((i, j, conf, homo.reshape(9), pts))
+            table.append((j, i, conf, inv.reshape(9), pts[:, [2, 3, 0, 1]]))
+    assert len(table) >= 2 * (n - 1)
+    cams = rd.take(np.float64, n * 13).reshape(n, 13)
+    shapes = np.array([[w, h]] * n, np.int32)
+    assert np.array_equal(cams, host.estimate(shapes, table))           # the program's host stage == the library entry
+    if ref_available():
+        assert np.array_equal(cams, ref_impl(Ref(PanoConfig())).estimate(shapes, table))
+    assert np.all(np.abs(cams[:, 0] / focal - 1) < 0.12) and reprojection_rms(cams, table) < 1.5
+    H, W = (int(x) for x in rd.take(np.int32, 2))
+    assert H > 150 and W > 600
+    pano = rd.take(np.float32, H * W * 3).reshape(H, W, 3)
+    homos = []
+    for k in range(n):                                                   # component.homo = R^-1 K^-1 (stitcher.cc:157)
+        Kc = np.array([[cams[k, 0], 0, cams[k, 2]], [0, cams[k, 0] * cams[k, 1], cams[k, 3]], [0, 0, 1.0]])
+        homos.append(cams[k, 4:].reshape(3, 3).T @ np.linalg.inv(Kc))
+    want, _ = orc.blend(views, np.stack(homos), 2, n >> 1, cfg)
+    assert want.shape == pano.shape
+    valid = (want[..., 0] >= 0) & (pano[..., 0] >= 0)
+    assert valid.mean() > 0.5 and np.mean((want[..., 0] >= 0) != (pano[..., 0] >= 0)) < 2e-3
+    assert np.abs(pano[valid] - want[valid]).max() < 1e-4            # warped pixels: BASELINE tolerance
+
+
 def test_reference_dropin():
     if not os.path.exists(DROPIN):
         pytest.skip("oracle/_ref/ref_dropin_test not built (reference sources absent at build time)")
