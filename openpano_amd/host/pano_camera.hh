@@ -361,6 +361,23 @@ class IncrementalBundleAdjuster {
 				auto dRtodviT = all_dRdvi[to];
 				for (auto& m : dRtodviT) m = m.transpose();
 				const Homography Hto_to_from = (fromK * c_from.R) * (toRinv * toKinv);
+				// The matrices below do not depend on the match: the reference forms them again for
+				// every point (:313-343); once per pair gives the same values.
+				const Homography Mfrom = c_from.R * toRinv * toKinv;                 // d/d(K_from): dK * (Mfrom p)
+				const Homography Prot = toRinv * toKinv;                             // d/d(R_from): (K_from dR_i) * (Prot p)
+				const Homography Bfrom[3] = {fromK * dRfromdvi[0], fromK * dRfromdvi[1], fromK * dRfromdvi[2]};
+				const Homography Mto = fromK * c_from.R * toRinv * toKinv;           // d/d(K_to): (Mto dK) * (-Kinv_to p)
+				const Homography Cto[3] = {Mto * dKdfocal, Mto * dKdppx, Mto * dKdppy};
+				const Homography Mrot = fromK * c_from.R;                            // d/d(R_to): (Mrot dR_i^T) * (Kinv_to p)
+				const Homography Dto[3] = {Mrot * dRtodviT[0], Mrot * dRtodviT[1], Mrot * dRtodviT[2]};
+
+				// This pair only touches the (from, to) rows/columns of JtJ and J^T r: work on a local
+				// 12 x 12 copy and put it back -- every entry still receives the same additions in the
+				// same order, from L1 instead of a 6n x 6n matrix.
+				int gi[12];
+				for (int i = 0; i < 6; ++i) { gi[i] = param_idx_from + i; gi[6 + i] = param_idx_to + i; }
+				double L[12][12], g[12];
+				for (int a = 0; a < 12; ++a) { g[a] = Jtr[gi[a]]; for (int b = 0; b < 12; ++b) L[a][b] = JtJ[(size_t)gi[a] * np + gi[b]]; }
 
 				for (const auto& p : pair.m.match) {
 					const Vec2D to2 = p.first;
@@ -371,52 +388,47 @@ class IncrementalBundleAdjuster {
 					auto drdv = [&](const Vec& dhdv) {
 						return Vec2D(-dhdv.x * hz_inv + dhdv.z * homo.x * hz_sqr_inv, -dhdv.y * hz_inv + dhdv.z * homo.y * hz_sqr_inv);
 					};
-					std::array<Vec2D, NR_PARAM_PER_CAMERA> dfrom, dto;
-					Homography m = c_from.R * toRinv * toKinv;
-					Vec dot_u2 = m.trans(to2);
-					dfrom[0] = drdv(dKdfocal.trans(dot_u2));
-					dfrom[1] = drdv(dKdppx.trans(dot_u2));
-					dfrom[2] = drdv(dKdppy.trans(dot_u2));
-					dot_u2 = (toRinv * toKinv).trans(to2);
-					dfrom[3] = drdv((fromK * dRfromdvi[0]).trans(dot_u2));
-					dfrom[4] = drdv((fromK * dRfromdvi[1]).trans(dot_u2));
-					dfrom[5] = drdv((fromK * dRfromdvi[2]).trans(dot_u2));
+					Vec2D d[12];                                   // 0..5: d/d(from params), 6..11: d/d(to params)
+					Vec dot_u2 = Mfrom.trans(to2);
+					d[0] = drdv(dKdfocal.trans(dot_u2));
+					d[1] = drdv(dKdppx.trans(dot_u2));
+					d[2] = drdv(dKdppy.trans(dot_u2));
+					dot_u2 = Prot.trans(to2);
+					d[3] = drdv(Bfrom[0].trans(dot_u2));
+					d[4] = drdv(Bfrom[1].trans(dot_u2));
+					d[5] = drdv(Bfrom[2].trans(dot_u2));
 					// d(Kinv)/dv = -Kinv dK/dv Kinv
-					m = fromK * c_from.R * toRinv * toKinv;
 					dot_u2 = toKinv.trans(to2) * (-1);
-					dto[0] = drdv((m * dKdfocal).trans(dot_u2));
-					dto[1] = drdv((m * dKdppx).trans(dot_u2));
-					dto[2] = drdv((m * dKdppy).trans(dot_u2));
-					m = fromK * c_from.R;
+					d[6] = drdv(Cto[0].trans(dot_u2));
+					d[7] = drdv(Cto[1].trans(dot_u2));
+					d[8] = drdv(Cto[2].trans(dot_u2));
 					dot_u2 = toKinv.trans(to2);
-					dto[3] = drdv((m * dRtodviT[0]).trans(dot_u2));
-					dto[4] = drdv((m * dRtodviT[1]).trans(dot_u2));
-					dto[5] = drdv((m * dRtodviT[2]).trans(dot_u2));
+					d[9] = drdv(Dto[0].trans(dot_u2));
+					d[10] = drdv(Dto[1].trans(dot_u2));
+					d[11] = drdv(Dto[2].trans(dot_u2));
 
 					// J^T r, the two rows of this match (J itself is never stored)
 					const double rx = residual[idx], ry = residual[idx + 1];
 					for (int i = 0; i < 6; ++i) {
-						Jtr[param_idx_from + i] += dfrom[i].x * rx; Jtr[param_idx_from + i] += dfrom[i].y * ry;
-						Jtr[param_idx_to + i] += dto[i].x * rx; Jtr[param_idx_to + i] += dto[i].y * ry;
+						g[i] += d[i].x * rx; g[i] += d[i].y * ry;
+						g[6 + i] += d[6 + i].x * rx; g[6 + i] += d[6 + i].y * ry;
 					}
-					// JtJ
+					// JtJ (:357-381)
 					for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-						const int i1 = param_idx_from + i, i2 = param_idx_to + j;
-						const double val = dfrom[i].dot(dto[j]);
-						JtJ[(size_t)i1 * np + i2] += val; JtJ[(size_t)i2 * np + i1] += val;
+						const double val = d[i].dot(d[6 + j]);
+						L[i][6 + j] += val; L[6 + j][i] += val;
 					}
 					for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) {
-						int i1 = param_idx_from + i, i2 = param_idx_from + j;
-						double val = dfrom[i].dot(dfrom[j]);
-						JtJ[(size_t)i1 * np + i2] += val;
-						if (i != j) JtJ[(size_t)i2 * np + i1] += val;
-						i1 = param_idx_to + i; i2 = param_idx_to + j;
-						val = dto[i].dot(dto[j]);
-						JtJ[(size_t)i1 * np + i2] += val;
-						if (i != j) JtJ[(size_t)i2 * np + i1] += val;
+						double val = d[i].dot(d[j]);
+						L[i][j] += val;
+						if (i != j) L[j][i] += val;
+						val = d[6 + i].dot(d[6 + j]);
+						L[6 + i][6 + j] += val;
+						if (i != j) L[6 + j][6 + i] += val;
 					}
 					idx += 2;
 				}
+				for (int a = 0; a < 12; ++a) { Jtr[gi[a]] = g[a]; for (int b = 0; b < 12; ++b) JtJ[(size_t)gi[a] * np + gi[b]] = L[a][b]; }
 			}
 		}
 };
