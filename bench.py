@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-blend", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-pipeline (ESTIMATE_CAMERA) section")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -342,6 +343,11 @@ def main():
     # ---------------- host-fed ingest (PCIe inclusive; never `value`) ----------------
     if world == 1 and not args.no_ingest:
         out["ingest"] = run_ingest(hip, ctx, cfg, views, k_rank, args)
+
+    # ---------------- whole Stitcher::build() on rendered rotating-camera views (N=1 only) ----------------
+    if world == 1 and not args.no_e2e and not args.no_match and not args.no_blend:
+        from bench_e2e import run_e2e
+        out["stitch_e2e"] = run_e2e(hip, ctx, args, log)
 
     # ---------------- CPU baseline (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

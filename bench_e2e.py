@@ -1,0 +1,90 @@
+"""bench.py's `stitch_e2e` section: the whole ESTIMATE_CAMERA branch of Stitcher::build()
+(stitch/stitcher.cc:32-64) on rendered rotating-camera views of BASELINE config 4's shape --
+device SIFT, all-pairs match, batched RANSAC, HOST camera estimation + bundle adjustment
+(openpano_amd/libpano_host.so, the Eigen-free mirror of camera_estimator.cc /
+incremental_bundle_adjuster.cc), device spherical blend.  Reported next to `value`, never as it."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _host_lib():
+    lib = C.CDLL(os.path.join(ROOT, "openpano_amd", "libpano_host.so"))
+    f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"); i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    lib.pano_estimate_cameras.argtypes = [C.c_int, i32, C.c_int, i32, f32, f64, i32, f64, f64]
+    lib.pano_homography_inverse.argtypes = [f64, f64]
+    return lib
+
+
+def run_e2e(hip, ctx, args, log):
+    from openpano_amd import synth
+    from openpano_amd.config import PanoConfig
+    n, H, W = args.images, 867, 1300
+    cfg = PanoConfig(ESTIMATE_CAMERA=1, ORDERED_INPUT=0, TRANS=0)
+    t0 = time.perf_counter()
+    views, focal, Rs = synth.rotating_views(n, H, W, seed=4000, step_deg=14.0, rows=2)
+    log(f"rendered {n} rotating-camera views {W}x{H} in {time.perf_counter() - t0:.1f} s")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_imgs = [torch.from_numpy(v).to(dev) for v in views]
+    inputs = [(t.data_ptr(), H, W) for t in d_imgs]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    shapes = np.array([[W, H]] * n, np.int32)
+    host = _host_lib()
+
+    def once():
+        st = {}
+        torch.cuda.synchronize(); t = time.perf_counter()
+        feats = hip.sift_batch(ctx, cfg, inputs)
+        st["sift"] = time.perf_counter() - t; t = time.perf_counter()
+        mh = hip.match_pairs_handle(ctx, cfg, feats, pairs)
+        st["match"] = time.perf_counter() - t; t = time.perf_counter()
+        rs = hip.ransac_pairs(ctx, cfg, feats, mh, pairs, shapes, base_seed=42)
+        st["ransac"] = time.perf_counter() - t; t = time.perf_counter()
+        # Stitcher::match_image's bookkeeping (stitcher.cc:79-93): both directions of every connected pair
+        coors = {}
+        ij, conf, homo, cnt, pts = [], [], [], [], []
+        for p, (i, j) in enumerate(pairs):
+            r = rs[p]
+            if not r["ok"]:
+                continue
+            for k in (i, j):
+                if k not in coors:
+                    coors[k] = feats.get(k)[1]
+            m = mh.get(p)
+            inl = r["inliers"]
+            a = coors[i][m[inl, 0]]; b = coors[j][m[inl, 1]]
+            hinv = np.zeros(9); host.pano_homography_inverse(np.ascontiguousarray(r["homo"].reshape(9)), hinv)
+            hinv = hinv / hinv[8]
+            ij += [[i, j], [j, i]]; conf += [r["confidence"]] * 2; homo += [r["homo"].reshape(9), hinv]
+            cnt += [len(inl)] * 2; pts += [np.concatenate([a, b], 1), np.concatenate([b, a], 1)]
+        st["pairwise table (host glue)"] = time.perf_counter() - t; t = time.perf_counter()
+        cams = np.zeros((n, 13))
+        host.pano_estimate_cameras(n, shapes.reshape(-1).copy(), len(ij), np.asarray(ij, np.int32).reshape(-1), np.asarray(conf, np.float32),
+                                   np.ascontiguousarray(np.stack(homo)).reshape(-1), np.asarray(cnt, np.int32),
+                                   np.ascontiguousarray(np.concatenate(pts)).reshape(-1), cams.reshape(-1))
+        st["camera estimation + bundle adjustment (host)"] = time.perf_counter() - t; t = time.perf_counter()
+        homos = []
+        for k in range(n):
+            Kc = np.array([[cams[k, 0], 0, cams[k, 2]], [0, cams[k, 0] * cams[k, 1], cams[k, 3]], [0, 0, 1.0]])
+            homos.append(cams[k, 4:].reshape(3, 3).T @ np.linalg.inv(Kc))
+        cv = hip.blend(ctx, cfg, inputs, np.stack(homos), 2, n >> 1)
+        torch.cuda.synchronize()
+        st["blend"] = time.perf_counter() - t
+        res = dict(canvas=[cv.h, cv.w], connected_pairs=len(ij) // 2, inlier_matches=int(sum(cnt) // 2), descriptors=int(feats.total),
+                   focal_estimated=float(np.median(cams[:, 0])), focal_rendered=float(focal))
+        cv.free(); mh.free(); feats.free()
+        return st, res
+
+    once()                                   # warm-up (allocation pool, kernels)
+    st, res = once()
+    total = sum(st.values())
+    res.update(images=n, image=[H, W], ms_total=total * 1e3, stage_ms={k: round(v * 1e3, 3) for k, v in st.items()},
+               note="wall clock per stage incl. the Python/ctypes glue of this driver; the reference's own CameraEstimator "
+                    "needs ~10 s for a table of this size (tests/test_camera_vs_ref.py scale), its CPU SIFT ~0.4 s per image-core")
+    return res

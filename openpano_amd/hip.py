@@ -402,6 +402,15 @@ class Matches:
     def __init__(self, handle, npairs):
         self.handle = handle; self.npairs = npairs
 
+    def get(self, p):
+        """(M, 2) int32 <idx in first, idx in second> of pair p."""
+        L = lib()
+        n = L.op_matches_count(self.handle, p)
+        a = np.empty((n, 2), np.int32)
+        if n:
+            check(L.op_matches_copy(self.handle, p, a.ctypes.data_as(C.c_void_p)))
+        return a
+
     def lists(self):
         L = lib(); out = []
         for p in range(self.npairs):

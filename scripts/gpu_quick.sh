@@ -4,7 +4,7 @@
 tag=${1:-q}; kexpr=${2:-"sift or match"}
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q -k "$kexpr" 2>&1 | tail -4
-python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ingest > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || tail -5 gpurun_out/${tag}_bench.err
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-e2e > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || tail -5 gpurun_out/${tag}_bench.err
 python - <<PY
 import json
 d=json.load(open("gpurun_out/${tag}_bench.json"))
