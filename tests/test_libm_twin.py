@@ -47,3 +47,20 @@ def test_abi_header_symbols_exported():
     assert not missing, missing
     lib.op_abi_version.restype = C.c_int
     assert lib.op_abi_version() >= 2
+
+
+def test_host_abi_header_symbols_exported():
+    """include/pano_host.h vs openpano_amd/libpano_host.so (host-only camera estimation entries)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "pano_host.h")).read()
+    names = sorted(set(re.findall(r"\b(pano_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 7
+    so = os.path.join(root, "openpano_amd", "libpano_host.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(so)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
