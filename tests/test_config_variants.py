@@ -15,10 +15,13 @@ VARIANTS = {
     "min_scales_1oct": dict(NUM_SCALE=6, NUM_OCTAVE=1),
     "max_scales_5oct": dict(NUM_SCALE=12, NUM_OCTAVE=5, SCALE_FACTOR=1.2),
     "window10_wide": dict(GAUSS_WINDOW_FACTOR=10, NUM_SCALE=9, SCALE_FACTOR=1.3),
+    "tiny_working_size": dict(SIFT_WORKING_SIZE=130, CONTRAST_THRES=1e-2, PRE_COLOR_THRES=2e-2),   # 149 x 111 working image, octaves down to 53 x 40: bands and segments smaller than a workgroup
+    "large_working_size": dict(SIFT_WORKING_SIZE=1500, NUM_OCTAVE=5),
     "thresholds": dict(CONTRAST_THRES=2e-2, PRE_COLOR_THRES=3e-2, EDGE_RATIO=10, JUDGE_EXTREMA_DIFF_THRES=1e-3,
                        ORI_RADIUS=3.5, ORI_HIST_SMOOTH_COUNT=1, DESC_HIST_SCALE_FACTOR=2, CALC_OFFSET_DEPTH=3),
 }
 EMPTY = ("no_scan_layer", "one_scan_layer_empty")
+FEW = ("tiny_working_size",)          # a 149 x 111 working image holds only a dozen keypoints
 
 
 def _view():
@@ -37,7 +40,7 @@ def test_oracle_equals_reference_under_config(ref, name):
         od, oc = sort_features(*Oracle(cfg).detect_feature(img))
     finally:
         ref.set_config(**{k: v for k, v in PanoConfig().raw_items()})
-    assert (len(rd) > 30) == (name not in EMPTY) and np.array_equal(rd, od) and np.array_equal(rc, oc)
+    assert ((len(rd) > 30) == (name not in EMPTY) or name in FEW) and np.array_equal(rd, od) and np.array_equal(rc, oc)
 
 
 @pytest.mark.gpu
@@ -52,5 +55,5 @@ def test_hip_equals_oracle_under_config(name):
     f = hip.sift_batch(ctx, cfg, [img, img])
     for k in range(2):
         d, c = f.get(k)
-        assert (len(d) > 30) == (name not in EMPTY) and np.array_equal(d, od) and np.array_equal(c, oc), (name, k)
+        assert ((len(d) > 30) == (name not in EMPTY) or name in FEW) and np.array_equal(d, od) and np.array_equal(c, oc), (name, k)
     f.free(); ctx.close()

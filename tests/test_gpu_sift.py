@@ -67,7 +67,8 @@ def _compare_stages(g, o, cfg):
     assert np.array_equal(g.coor, o.coor)
 
 
-VIEWS = [("cfg2_600x400", 400, 600, 22), ("cfg4_1300x867", 867, 1300, 38), ("odd_333x777", 333, 777, 5)]
+VIEWS = [("cfg2_600x400", 400, 600, 22), ("cfg4_1300x867", 867, 1300, 38), ("odd_333x777", 333, 777, 5),
+         ("strip_150x1250", 150, 1250, 9), ("tower_1250x150", 1250, 150, 10)]      # one band / one segment extremes of the row-streaming kernel
 
 
 @pytest.mark.parametrize("name,h,w,seed", VIEWS, ids=[v[0] for v in VIEWS])
