@@ -127,7 +127,18 @@ def run_ingest(hip, ctx, cfg, views, k_rank, args):
     u8 = [(v * 255 + 0.5).astype(np.uint8) for v in views]
     f32 = [(v.astype(np.float64) / 255.0).astype(np.float32) for v in u8]
     for key, imgs in (("host_fp32", f32), ("host_uint8", u8)):
-        pinned = [torch.from_numpy(x).pin_memory().numpy() for x in imgs]      # page-locked like a decoder's output pool
+        # page-locked like a decoder's output pool: ONE pinned block sliced into the images (38 separate
+        # pin_memory() calls went through PyTorch's caching host allocator, whose small-block path
+        # produced 5x slower H2D copies for the uint8 images when large device buffers had been
+        # cycled before -- an artefact of the driver program, not of the library)
+        stride = (imgs[0].nbytes + 255) & ~255
+        block = torch.empty(stride * len(imgs), dtype=torch.uint8).pin_memory()
+        flat = block.numpy()
+        pinned = []
+        for k, x in enumerate(imgs):
+            v = flat[k * stride: k * stride + x.nbytes].view(x.dtype).reshape(x.shape)
+            v[...] = x
+            pinned.append(v)
         f = hip.sift_batch(ctx, cfg, pinned); k = int(f.total); f.free()
         steps = max(1, min(args.steps, 5))
         torch.cuda.synchronize(); t0 = time.perf_counter()

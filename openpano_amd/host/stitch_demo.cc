@@ -4,7 +4,9 @@
 //   replaced here by chaining the pairwise homographies to the middle image] -> blend,
 // written with the reference's class and method names.
 //
-//   stitch_demo <in.bin> <out.bin> [base_seed] [camera]
+//   stitch_demo <in.bin> <out.bin> [base_seed] [camera|camera_ordered]
+// ("camera_ordered": ORDERED_INPUT 1 as in BASELINE configs 2-3 -- only (i, i+1 mod n) are matched,
+// Stitcher::linear_pairwise_match, stitcher.cc:115-136; head and tail need not connect.)
 // With "camera" the program runs the ESTIMATE_CAMERA branch of Stitcher::build() instead (BASELINE
 // configs 2-4): all pairs matched, homography RANSAC, host camera estimation + bundle adjustment
 // (pano_camera.hh), spherical blend; out.bin then carries n*13 f64 cameras (focal, aspect, ppx,
@@ -68,7 +70,7 @@ static void put_pairs(FILE* fo, const HipFeatureSet& fs, const std::vector<std::
 
 // Stitcher::build() under ESTIMATE_CAMERA (stitch/stitcher.cc:32-64), stage by stage so that every
 // intermediate can be written out
-static int run_camera_mode(const std::vector<Mat32f>& mats, const char* out_path, uint32_t base_seed) {
+static int run_camera_mode(const std::vector<Mat32f>& mats, const char* out_path, uint32_t base_seed, bool ordered) {
 	Stitcher st(mats, base_seed);
 	FILE* fo = fopen(out_path, "wb");
 	if (!fo) { perror(out_path); return 2; }
@@ -77,12 +79,13 @@ static int run_camera_mode(const std::vector<Mat32f>& mats, const char* out_path
 	const int n = (int)mats.size();
 	st.pairwise_matches.assign(n, std::vector<MatchInfo>(n));
 	std::vector<std::pair<int, int>> tasks;
-	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) tasks.emplace_back(i, j);
+	if (ordered) for (int i = 0; i < n; ++i) tasks.emplace_back(i, (i + 1) % n);
+	else for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) tasks.emplace_back(i, j);
 	std::vector<Shape2D> shapes;
 	for (auto& r : st.imgs) shapes.push_back(r.shape());
 	auto infos = hip_match_images(st.feats, shapes, tasks, base_seed);
 	put_pairs(fo, st.feats, tasks, infos);
-	st.record_matches(tasks, infos, false);
+	st.record_matches(tasks, infos, ordered);
 	st.assign_center();
 	st.estimate_camera();
 	for (auto& c : st.cameras) {
@@ -115,10 +118,11 @@ int main(int argc, char** argv) {
 		if (fread(mats.back().ptr(), sizeof(float), (size_t)h * w * 3, fi) != (size_t)h * w * 3) return 2;
 	}
 	fclose(fi);
-	const bool camera_mode = argc > 4 && std::string(argv[4]) == "camera";
-	config::ORDERED_INPUT = !camera_mode; config::ESTIMATE_CAMERA = camera_mode; config::TRANS = !camera_mode;   // TRANS mode: affine RANSAC, flat blend
+	const std::string mode = argc > 4 ? argv[4] : "";
+	const bool camera_mode = mode == "camera" || mode == "camera_ordered";
+	config::ORDERED_INPUT = !camera_mode || mode == "camera_ordered"; config::ESTIMATE_CAMERA = camera_mode; config::TRANS = !camera_mode;   // TRANS mode: affine RANSAC, flat blend
 	config::LAZY_READ = false;
-	if (camera_mode) return run_camera_mode(mats, argv[2], base_seed);
+	if (camera_mode) return run_camera_mode(mats, argv[2], base_seed, mode == "camera_ordered");
 
 	// ---- StitcherBase::calc_feature (stitch/stitcherbase.cc:9-27)
 	std::vector<ImageRef> imgs;

@@ -4,7 +4,7 @@
 # FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots), MI355X_MICROARCH.md "rocprofv3 PMC slots".
 # Usage: scripts/gpu_pmc.sh <tag> [bench args]   -> gpurun_out/<tag>_pmc_{fetch,write,sq}/...csv
 tag=${1:-r01}; shift
-args=${@:---steps 2 --warmup 1 --no-cpu-baseline}
+args=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 run() {  # name, counters...

@@ -96,7 +96,8 @@ def test_stitch_demo(tmp_path, oracle, n, h, w, seed):
     assert np.array_equal(pano, want)          # flat projection: no transcendental -> bit-exact
 
 
-def test_stitch_demo_estimate_camera(tmp_path, oracle):
+@pytest.mark.parametrize("ordered", [False, True], ids=["all_pairs", "ordered_input"])
+def test_stitch_demo_estimate_camera(tmp_path, oracle, ordered):
     """The ESTIMATE_CAMERA branch of Stitcher::build() end to end in the standalone C++ program
     (device SIFT / match / RANSAC, host camera estimation + bundle adjustment, device spherical
     blend): features, matches and RANSAC results against the CPU oracle, the cameras against the
@@ -111,10 +112,11 @@ def test_stitch_demo_estimate_camera(tmp_path, oracle):
         for v in views:
             f.write(np.ascontiguousarray(v, np.float32).tobytes())
     base_seed = 42
-    r = subprocess.run([DEMO, str(fin), str(fout), str(base_seed), "camera"], capture_output=True, text=True, env=_env(), timeout=300)
+    r = subprocess.run([DEMO, str(fin), str(fout), str(base_seed), "camera_ordered" if ordered else "camera"], capture_output=True,
+                       text=True, env=_env(), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     rd = _Reader(open(fout, "rb").read())
-    cfg = PanoConfig(ESTIMATE_CAMERA=1, TRANS=0, ORDERED_INPUT=0, LAZY_READ=0)
+    cfg = PanoConfig(ESTIMATE_CAMERA=1, TRANS=0, ORDERED_INPUT=int(ordered), LAZY_READ=0)
     from checkers import Oracle, ref_available, Ref
     from camera_util import host_impl, ref_impl, reprojection_rms
     orc = Oracle(cfg)
@@ -126,7 +128,7 @@ def test_stitch_demo_estimate_camera(tmp_path, oracle):
         assert K > 100 and np.array_equal(d, od) and np.array_equal(c, oc), f"image {k}"
         descs.append(d); coors.append(c)
     npairs = int(rd.take(np.int32, 1)[0])
-    assert npairs == n * (n - 1) // 2
+    assert npairs == (n if ordered else n * (n - 1) // 2)          # ordered: (i, i+1 mod n), stitcher.cc:121-122
     host = host_impl()
     table = []
     for p in range(npairs):
