@@ -76,6 +76,7 @@ def main():
     print("match_ab", len(sa.desc), len(sb.desc), "->", len(pairs))
     blend_case(ref)
     ransac_case(ref, sa, sb, pairs)
+    camera_case(ref)
 
 
 def ransac_case(ref, sa, sb, pairs):
@@ -113,5 +114,27 @@ def blend_case(ref):
     print("blend_sph_linear", lin.shape, "covered", float((lin[..., 0] >= 0).mean()))
 
 
+def camera_case(ref):
+    """CameraEstimator::estimate of the reference (its Eigen calls go to the stand-in of
+    oracle/ref_shim -- DESIGN.md, "parity unpinned at Eigen") on the pairwise MatchInfo table of a
+    synthetic rotating-camera scene, in the shipped configuration (MULTIPASS_BA 1, STRAIGHTEN 1,
+    LM_LAMBDA 5) and with the one-shot bundle adjustment (MULTIPASS_BA 0, no straightening)."""
+    from camera_util import ref_impl, rotating_camera_scene
+    refc = ref_impl(ref)
+    shapes, table, (focal, Rs) = rotating_camera_scene(11, n=8, rows=2, step_deg=15.0, npts=160)
+    out = dict(shapes=shapes, ij=np.array([[t[0], t[1]] for t in table], np.int32), conf=np.array([t[2] for t in table], np.float32),
+               homo=np.stack([t[3] for t in table]), cnt=np.array([len(t[4]) for t in table], np.int32),
+               pts=np.concatenate([t[4] for t in table]), focal=np.float64(focal))
+    for name, mode in (("shipped", dict(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0)), ("oneshot", dict(MULTIPASS_BA=0, STRAIGHTEN=0, LM_LAMBDA=5.0))):
+        refc.config(**mode)
+        out["cameras_" + name] = refc.estimate(shapes, table)
+    refc.config(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0)
+    np.savez_compressed(os.path.join(HERE, "camera_scene.npz"), **out)
+    print("camera_scene", len(shapes), "images", len(table) // 2, "pairs", int(out["cnt"].sum()) // 2, "matches; focal", out["cameras_shipped"][:, 0].round(2))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "camera":
+        camera_case(Ref(PanoConfig()))
+    else:
+        main()

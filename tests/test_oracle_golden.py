@@ -112,3 +112,24 @@ def test_ransac_oracle_matches_golden(oracle):
     g = np.load(os.path.join(HERE, "golden", "ransac_ab.npz"))
     cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
     _ransac_golden_check(lambda m, ca, cb, sh, seed, aff: oracle.ransac(m, ca, cb, sh, sh, seed, cfg=cyl if aff else None), g)
+
+
+def test_camera_estimation_golden():
+    """openpano_amd/libpano_host.so against cameras the reference's own CameraEstimator produced
+    (tests/golden/make_golden.py camera): runs anywhere, no oracle/_ref needed."""
+    import os
+    from camera_util import host_impl
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_scene.npz"))
+    table, at = [], 0
+    for e in range(len(g["ij"])):
+        c = int(g["cnt"][e])
+        table.append((int(g["ij"][e, 0]), int(g["ij"][e, 1]), float(g["conf"][e]), g["homo"][e], g["pts"][at: at + c])); at += c
+    host = host_impl()
+    for name, mode in (("shipped", dict(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0)), ("oneshot", dict(MULTIPASS_BA=0, STRAIGHTEN=0, LM_LAMBDA=5.0))):
+        host.config(**mode)
+        try:
+            cams = host.estimate(g["shapes"], table)
+        finally:
+            host.config(MULTIPASS_BA=1, STRAIGHTEN=1, LM_LAMBDA=5.0)
+        assert np.array_equal(cams, g["cameras_" + name]), name
+        assert np.all(np.abs(cams[:, 0] / float(g["focal"]) - 1) < 0.03)
