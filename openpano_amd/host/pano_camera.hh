@@ -376,59 +376,53 @@ class IncrementalBundleAdjuster {
 				// same order, from L1 instead of a 6n x 6n matrix.
 				int gi[12];
 				for (int i = 0; i < 6; ++i) { gi[i] = param_idx_from + i; gi[6 + i] = param_idx_to + i; }
+				// Upper triangle only: the reference adds the same value to JtJ(a, b) and JtJ(b, a)
+				// (:357-381), so the two stay bit-equal and the lower half is a copy at write-back.
 				double L[12][12], g[12];
-				for (int a = 0; a < 12; ++a) { g[a] = Jtr[gi[a]]; for (int b = 0; b < 12; ++b) L[a][b] = JtJ[(size_t)gi[a] * np + gi[b]]; }
+				for (int a = 0; a < 12; ++a) { g[a] = Jtr[gi[a]]; for (int b = a; b < 12; ++b) L[a][b] = JtJ[(size_t)gi[a] * np + gi[b]]; }
 
 				for (const auto& p : pair.m.match) {
 					const Vec2D to2 = p.first;
 					const Vec homo = Hto_to_from.trans(to2);
 					const double hz_sqr_inv = 1.0 / pano_sqr((float)homo.z);
 					const double hz_inv = 1.0 / homo.z;
-					// d(residual)/d(variable) = -d(point 2d)/d(homo 3d) * d(homo 3d)/d(variable)
-					auto drdv = [&](const Vec& dhdv) {
-						return Vec2D(-dhdv.x * hz_inv + dhdv.z * homo.x * hz_sqr_inv, -dhdv.y * hz_inv + dhdv.z * homo.y * hz_sqr_inv);
+					// d(residual)/d(variable) = -d(point 2d)/d(homo 3d) * d(homo 3d)/d(variable);
+					// dx / dy: 0..5 = d/d(from params), 6..11 = d/d(to params)
+					double dx[12], dy[12];
+					auto drdv = [&](int k, const Vec& dhdv) {
+						dx[k] = -dhdv.x * hz_inv + dhdv.z * homo.x * hz_sqr_inv;
+						dy[k] = -dhdv.y * hz_inv + dhdv.z * homo.y * hz_sqr_inv;
 					};
-					Vec2D d[12];                                   // 0..5: d/d(from params), 6..11: d/d(to params)
 					Vec dot_u2 = Mfrom.trans(to2);
-					d[0] = drdv(dKdfocal.trans(dot_u2));
-					d[1] = drdv(dKdppx.trans(dot_u2));
-					d[2] = drdv(dKdppy.trans(dot_u2));
+					drdv(0, dKdfocal.trans(dot_u2));
+					drdv(1, dKdppx.trans(dot_u2));
+					drdv(2, dKdppy.trans(dot_u2));
 					dot_u2 = Prot.trans(to2);
-					d[3] = drdv(Bfrom[0].trans(dot_u2));
-					d[4] = drdv(Bfrom[1].trans(dot_u2));
-					d[5] = drdv(Bfrom[2].trans(dot_u2));
+					drdv(3, Bfrom[0].trans(dot_u2));
+					drdv(4, Bfrom[1].trans(dot_u2));
+					drdv(5, Bfrom[2].trans(dot_u2));
 					// d(Kinv)/dv = -Kinv dK/dv Kinv
 					dot_u2 = toKinv.trans(to2) * (-1);
-					d[6] = drdv(Cto[0].trans(dot_u2));
-					d[7] = drdv(Cto[1].trans(dot_u2));
-					d[8] = drdv(Cto[2].trans(dot_u2));
+					drdv(6, Cto[0].trans(dot_u2));
+					drdv(7, Cto[1].trans(dot_u2));
+					drdv(8, Cto[2].trans(dot_u2));
 					dot_u2 = toKinv.trans(to2);
-					d[9] = drdv(Dto[0].trans(dot_u2));
-					d[10] = drdv(Dto[1].trans(dot_u2));
-					d[11] = drdv(Dto[2].trans(dot_u2));
+					drdv(9, Dto[0].trans(dot_u2));
+					drdv(10, Dto[1].trans(dot_u2));
+					drdv(11, Dto[2].trans(dot_u2));
 
 					// J^T r, the two rows of this match (J itself is never stored)
 					const double rx = residual[idx], ry = residual[idx + 1];
-					for (int i = 0; i < 6; ++i) {
-						g[i] += d[i].x * rx; g[i] += d[i].y * ry;
-						g[6 + i] += d[6 + i].x * rx; g[6 + i] += d[6 + i].y * ry;
-					}
-					// JtJ (:357-381)
-					for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-						const double val = d[i].dot(d[6 + j]);
-						L[i][6 + j] += val; L[6 + j][i] += val;
-					}
-					for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) {
-						double val = d[i].dot(d[j]);
-						L[i][j] += val;
-						if (i != j) L[j][i] += val;
-						val = d[6 + i].dot(d[6 + j]);
-						L[6 + i][6 + j] += val;
-						if (i != j) L[6 + j][6 + i] += val;
-					}
+					for (int a = 0; a < 12; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
+					// JtJ: every entry gets  += d_a . d_b  (Vec2D::dot: x*x' + y*y')
+					for (int a = 0; a < 12; ++a)
+						for (int b = a; b < 12; ++b) L[a][b] += dx[a] * dx[b] + dy[a] * dy[b];
 					idx += 2;
 				}
-				for (int a = 0; a < 12; ++a) { Jtr[gi[a]] = g[a]; for (int b = 0; b < 12; ++b) JtJ[(size_t)gi[a] * np + gi[b]] = L[a][b]; }
+				for (int a = 0; a < 12; ++a) {
+					Jtr[gi[a]] = g[a];
+					for (int b = a; b < 12; ++b) { JtJ[(size_t)gi[a] * np + gi[b]] = L[a][b]; JtJ[(size_t)gi[b] * np + gi[a]] = L[a][b]; }
+				}
 			}
 		}
 };
