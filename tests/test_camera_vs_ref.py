@@ -120,3 +120,31 @@ def test_unconnected_image_is_an_error(host):
             "s, t, _ = rotating_camera_scene(1, n=5); t = [e for e in t if 4 not in (e[0], e[1])]; host_impl().estimate(s, t)") % __import__("os").path.dirname(__file__)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and "Found a tree of size 4!=5" in p.stderr and "not connected well" in p.stderr
+
+
+def test_linear_algebra_properties(host):
+    """pano_la.hh on its own terms (no reference needed): orthogonality of the SVD-derived rotation,
+    inverse and QR residuals over randomly conditioned inputs, the rank-deficient branch."""
+    rng = np.random.default_rng(12)
+    for _ in range(100):
+        M = rng.normal(0, 1, (3, 3))
+        if abs(np.linalg.det(M)) < 1e-3:
+            continue
+        v = host.rotation_to_angle(M)                      # nearest rotation of an arbitrary matrix
+        R = host.angle_to_rotation(v)
+        U, _, Vt = np.linalg.svd(M); Rn = U @ Vt
+        if np.linalg.det(Rn) < 0:
+            Rn = -Rn
+        if np.arccos(np.clip((np.trace(Rn) - 1) / 2, -1, 1)) < 3.0:       # away from the pi ambiguity of the axis
+            assert np.allclose(R, Rn, atol=1e-9)
+        ok, inv = host.inverse(M)
+        assert ok and np.allclose(inv @ M, np.eye(3), atol=1e-9 * np.linalg.cond(M))
+    for n, cond in ((6, 1e3), (30, 1e8), (90, 1e12)):
+        Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        A = (Q * np.geomspace(1, 1 / cond, n)) @ Q.T
+        x0 = rng.normal(size=n); b = A @ x0
+        x = host.solve(A, b)
+        assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b) * n
+    A = np.diag([3.0, 2.0, 0.0, 0.0]); A[0, 1] = A[1, 0] = 1.0
+    x = host.solve(A, np.array([1.0, 1.0, 0.0, 0.0]))       # rank 2: the free unknowns stay 0
+    assert np.allclose(A @ x, [1, 1, 0, 0]) and np.all(x[2:] == 0)
