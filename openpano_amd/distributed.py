@@ -1,44 +1,74 @@
-"""Multi-GPU exchange step of the hot path.
+"""Multi-GPU exchange step and sharded job of the hot path.
 
-SIFT shards by image with no communication.  All-pairs matching needs every image's
-descriptors on every rank: ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) of the
-per-image counts followed by one of the (padded) descriptor payload; the unordered pair list of
-``Stitcher::pairwise_match`` (stitch/stitcher.cc:100) is then dealt round-robin to the ranks.
+One process per GPU.  SIFT shards by image with no communication (stitcherbase.cc:14 is the axis).
+All-pairs matching needs every image's features on every rank: ONE bucketed all-gather (RCCL over
+xGMI on GPUs, gloo in the CPU tests) of a per-rank byte bucket ``[descriptors K x 128 fp32 |
+coordinates K x 2 fp64]`` after a tiny all-gather of the per-image counts; the unordered pair list
+of ``Stitcher::pairwise_match`` (stitch/stitcher.cc:100) is dealt to the ranks balanced by
+``K_i * K_j``; RANSAC follows the pair partition; the per-pair results (KBs) are all-gathered so
+that rank 0 -- which runs the host-only camera estimation and the blend -- holds the whole job.
 torch.distributed is plumbing here: tensors in, tensors out, no model code.
+
+``ShardedJob`` is engine-agnostic: the product engine is ``HipEngine`` (the C-ABI library); the
+CPU tests drive the same exchange / partition / gather code with an oracle-backed engine.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
-def allgather_descriptors(local_desc: torch.Tensor, local_counts, group=None):
-    """local_desc: (sum(local_counts), 128) float32 on this rank's device (images back to back).
+# ----------------------------------------------------------------------------- exchange
+def allgather_features(local_desc: torch.Tensor, local_coor: torch.Tensor | None, local_counts, group=None):
+    """local_desc: (K, 128) float32, local_coor: (K, 2) float64 or None, on this rank's device,
+    images back to back; local_counts: descriptors per local image.
 
-    Returns (global_desc, global_counts): the same layout for the images of rank 0, 1, ... in
-    rank order -- identical on every rank.
-    """
+    Returns (global_desc, global_coor | None, global_counts, images_per_rank): the same layout
+    for the images of rank 0, 1, ... in rank order -- identical on every rank.  Two collectives:
+    counts (N x int64, padded), then one byte bucket per rank padded to the largest shard."""
     world = dist.get_world_size(group)
     dev = local_desc.device
     cnt = torch.as_tensor(list(local_counts), dtype=torch.int64, device=dev)
-    ncnt = torch.tensor([cnt.numel()], dtype=torch.int64, device=dev)
-    all_n = [torch.empty_like(ncnt) for _ in range(world)]
-    dist.all_gather(all_n, ncnt, group=group)
-    nmax = int(max(int(x) for x in all_n))
-    cnt_pad = torch.zeros(nmax, dtype=torch.int64, device=dev)
-    cnt_pad[: cnt.numel()] = cnt
-    all_cnt = [torch.empty_like(cnt_pad) for _ in range(world)]
-    dist.all_gather(all_cnt, cnt_pad, group=group)
-    per_rank = [c[: int(n)] for c, n in zip(all_cnt, all_n)]
-    totals = [int(c.sum()) for c in per_rank]
-    mx = max(max(totals), 1)
-    pad = torch.zeros((mx, 128), dtype=torch.float32, device=dev)
-    pad[: local_desc.shape[0]] = local_desc
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    glob = torch.cat([o[:t] for o, t in zip(out, totals)], dim=0).contiguous()
-    counts = [int(v) for c in per_rank for v in c.tolist()]
-    return glob, counts
+    k_local = int(local_desc.shape[0])
+    assert int(cnt.sum()) == k_local
+    # header: [n_images, K, counts...] padded to a common length (image counts may differ by one)
+    nmax_t = torch.tensor([cnt.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=group)
+    nmax = int(nmax_t)
+    hdr = torch.zeros(nmax + 2, dtype=torch.int64, device=dev)
+    hdr[0] = cnt.numel(); hdr[1] = k_local; hdr[2: 2 + cnt.numel()] = cnt
+    all_hdr = torch.empty(world * (nmax + 2), dtype=torch.int64, device=dev)        # flat: gloo chunks along dim 0
+    dist.all_gather_into_tensor(all_hdr, hdr, group=group)
+    all_hdr = all_hdr.view(world, nmax + 2).cpu()
+    nimg = [int(all_hdr[r, 0]) for r in range(world)]
+    totals = [int(all_hdr[r, 1]) for r in range(world)]
+    counts = [int(v) for r in range(world) for v in all_hdr[r, 2: 2 + nimg[r]].tolist()]
+    per_kp = 128 * 4 + (16 if local_coor is not None else 0)
+    kmax = max(max(totals), 1)
+    bucket = torch.zeros(kmax * per_kp, dtype=torch.uint8, device=dev)
+    if k_local:
+        bucket[: k_local * 512] = local_desc.contiguous().view(torch.uint8).reshape(-1)
+        if local_coor is not None:
+            bucket[kmax * 512: kmax * 512 + k_local * 16] = local_coor.contiguous().view(torch.uint8).reshape(-1)
+    out = torch.empty(world * kmax * per_kp, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, bucket, group=group)
+    out = out.view(world, kmax * per_kp)
+    descs, coors = [], []
+    for r in range(world):
+        k = totals[r]
+        descs.append(out[r, : k * 512].view(torch.float32).reshape(k, 128))
+        if local_coor is not None:
+            coors.append(out[r, kmax * 512: kmax * 512 + k * 16].view(torch.float64).reshape(k, 2))
+    gdesc = torch.cat(descs, 0).contiguous()
+    gcoor = torch.cat(coors, 0).contiguous() if local_coor is not None else None
+    return gdesc, gcoor, counts, nimg
+
+
+def allgather_descriptors(local_desc: torch.Tensor, local_counts, group=None):
+    """Descriptor-only form of ``allgather_features`` -> (global_desc, global_counts)."""
+    g, _, counts, _ = allgather_features(local_desc, None, local_counts, group)
+    return g, counts
 
 
 def all_pairs(n: int):
@@ -63,32 +93,181 @@ def partition_pairs(pairs, rank: int, world: int, counts=None):
     return sorted(mine)
 
 
-def gather_match_results(pairs, match_lists, device, group=None):
+def shard_images(n: int, rank: int, world: int):
+    """Global image ids owned by ``rank``: round-robin, so every rank gets n/world +- 1 images."""
+    return list(range(rank, n, world))
+
+
+def _allgather_blob(blob: np.ndarray, device, group=None):
+    """variable-length int64 arrays of every rank -> list (rank order); one size + one payload collective"""
+    world = dist.get_world_size(group)
+    size = torch.tensor([blob.size], dtype=torch.int64, device=device)
+    sizes = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, size, group=group)
+    sizes = sizes.cpu().tolist()
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.int64, device=device)
+    if blob.size:
+        buf[: blob.size] = torch.from_numpy(np.ascontiguousarray(blob, np.int64)).to(device)
+    out = torch.empty(world * mx, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.view(world, mx).cpu().numpy()
+    return [out[r, : sizes[r]] for r in range(world)]
+
+
+def gather_match_results(pairs, match_lists, device, group=None, extras=None):
     """Step 3 of SURVEY 8(e): every rank matched its share of the pair list; the index pairs (a few
     KB per image pair) are collected so that rank 0 -- which runs the host-only camera estimation
     and the blend -- holds the whole job.  pairs: this rank's (i, j) list; match_lists: one (M, 2)
-    int32 array per pair.  Returns {(i, j): (M, 2) array} of ALL ranks (identical on every rank: the
-    exchange is an all-gather, cheap at this size and free of a root bottleneck over xGMI)."""
-    import numpy as np
-    world = dist.get_world_size(group)
-    # header: (i, j, count) per pair, then the flat index pairs
+    int32 array per pair; extras: optional per-pair float64 vectors of equal length (the RANSAC
+    result: ok, confidence, 9 homography entries, ...) carried bit-exactly as int64 views.
+    Returns {(i, j): (M, 2) array} or {(i, j): ((M, 2) array, extra)} of ALL ranks (identical on
+    every rank: an all-gather, cheap at this size and free of a root bottleneck over xGMI)."""
+    ne = len(extras[0]) if extras else 0
     hdr = np.array([[i, j, len(m)] for (i, j), m in zip(pairs, match_lists)], np.int64).reshape(-1, 3)
-    flat = np.concatenate([np.asarray(m, np.int64).reshape(-1, 2) for m in match_lists] + [np.zeros((0, 2), np.int64)])
-    sizes = torch.tensor([hdr.shape[0], flat.shape[0]], dtype=torch.int64, device=device)
-    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    mh = max(1, max(int(s[0]) for s in all_sizes)); mf = max(1, max(int(s[1]) for s in all_sizes))
-    buf = torch.zeros((mh * 3 + mf * 2,), dtype=torch.int64, device=device)
-    buf[: hdr.size] = torch.from_numpy(hdr.reshape(-1)).to(device)
-    buf[mh * 3: mh * 3 + flat.size] = torch.from_numpy(flat.reshape(-1)).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
+    flat = np.concatenate([np.asarray(m, np.int64).reshape(-1) for m in match_lists] + [np.zeros(0, np.int64)])
+    ex = np.concatenate([np.ascontiguousarray(e, np.float64).view(np.int64) for e in extras] + [np.zeros(0, np.int64)]) if extras else np.zeros(0, np.int64)
+    blob = np.concatenate([np.array([hdr.shape[0], ne], np.int64), hdr.reshape(-1), flat, ex])
     res = {}
-    for o, s in zip(out, all_sizes):
-        o = o.cpu().numpy()
-        h = o[: int(s[0]) * 3].reshape(-1, 3); f = o[mh * 3: mh * 3 + int(s[1]) * 2].reshape(-1, 2)
+    for b in _allgather_blob(blob, device, group):
+        npair, ne_r = int(b[0]), int(b[1])
+        h = b[2: 2 + 3 * npair].reshape(-1, 3)
+        nflat = int(h[:, 2].sum()) * 2 if npair else 0
+        f = b[2 + 3 * npair: 2 + 3 * npair + nflat].reshape(-1, 2)
+        e = b[2 + 3 * npair + nflat:].view(np.float64).reshape(npair, ne_r) if ne_r else None
         at = 0
-        for i, j, c in h:
-            res[(int(i), int(j))] = f[at: at + int(c)].astype(np.int32)
+        for k, (i, j, c) in enumerate(h):
+            m = f[at: at + int(c)].astype(np.int32)
+            res[(int(i), int(j))] = (m, e[k].copy()) if e is not None else m
             at += int(c)
     return res
+
+
+# ----------------------------------------------------------------------------- engines
+class HipEngine:
+    """The product engine: libopenpano_hip.so through the C-ABI (openpano_amd/hip.py)."""
+
+    def __init__(self, ctx, cfg, device):
+        from . import hip
+        self.hip, self.ctx, self.cfg, self.device = hip, ctx, cfg, device
+        self._feats = None
+
+    def sift(self, images):
+        """-> (desc (K,128) f32 tensor, coor (K,2) f64 tensor, counts); zero-copy views of the
+        library-owned buffers, valid until the next sift() of this engine."""
+        if self._feats is not None:
+            self._feats.free()
+        f = self._feats = self.hip.sift_batch(self.ctx, self.cfg, images) if not callable(images) else images()
+        counts = [f.count(i) for i in range(f.num_images)]
+        if int(f.total) == 0:
+            return torch.zeros((0, 128), device=self.device), torch.zeros((0, 2), dtype=torch.float64, device=self.device), counts
+        desc = torch.as_tensor(f.desc_device_array(), device=self.device)
+        coor = torch.as_tensor(f.coor_device_array(), device=self.device)
+        return desc, coor, counts
+
+    def table(self, desc, coor, counts):
+        """image-indexed feature table in this rank's HBM (op_features_from_device)"""
+        return self.hip.Features.from_device(self.ctx, desc.data_ptr(), counts, coor.data_ptr() if coor is not None else None)
+
+    def match(self, table, pairs):
+        """-> (handle, [(M,2) int32])"""
+        mh = self.hip.match_pairs_handle(self.ctx, self.cfg, table, pairs)
+        return mh, mh.lists()
+
+    def match_only(self, table, pairs):
+        self.hip.match_pairs_handle(self.ctx, self.cfg, table, pairs).free()
+
+    def ransac(self, table, mh, lists, pairs, shapes_wh, seeds):
+        return self.hip.ransac_pairs(self.ctx, self.cfg, table, mh, pairs, shapes_wh, seeds=seeds)
+
+    def free(self, obj):
+        obj.free()
+
+
+def ransac_extra(r):
+    """RANSAC result of one pair -> fixed-length float64 vector (carried by gather_match_results)"""
+    return np.concatenate([[float(r["ok"]), float(r["confidence"]), float(r["best_hyp"]), float(r["best_count"])], np.asarray(r["homo"], np.float64).reshape(9)])
+
+
+class ShardedJob:
+    """One stitching job (n images, all unordered pairs) sharded over the ranks of ``group``.
+
+    Phases (each can be timed separately by the caller):
+      sift(local_images)  -> this rank's features;        no communication
+      exchange()          -> global feature table on every rank;  the one all-gather
+      match()             -> this rank's share of the pair list
+      ransac(shapes, seed)-> TransformEstimation on the same share
+      gather()            -> {(gi, gj): (matches, ransac vector)} of the whole job on every rank
+    Image ids are GLOBAL (0..n-1); rank r owns ``shard_images(n, r, world)``; the exchanged table is
+    in global order and per-pair RANSAC seeds derive from the ids, so every result is independent of
+    the world size (tests/test_distributed_cpu.py compares world 2 with world 1)."""
+
+    def __init__(self, engine, n_images: int, device, group=None):
+        self.e = engine
+        self.n = n_images
+        self.device = device
+        self.group = group
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.dist else 0
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.local_ids = shard_images(n_images, self.rank, self.world)
+        self.tab = None; self.mh = None
+
+    def sift(self, local_images):
+        assert callable(local_images) or len(local_images) == len(self.local_ids)
+        self.desc, self.coor, self.counts = self.e.sift(local_images)
+        return sum(self.counts)
+
+    def exchange(self):
+        if self.world > 1:
+            gdesc, gcoor, rcounts, nimg = allgather_features(self.desc, self.coor, self.counts, self.group)
+            owner_order = [g for r in range(self.world) for g in shard_images(self.n, r, self.world)]
+            assert [len(shard_images(self.n, r, self.world)) for r in range(self.world)] == nimg
+            # the bucket arrives rank-major; the table is rebuilt in GLOBAL image order so that pair
+            # (i, j), its match list and its RANSAC draw sequence are those of the single-rank job
+            offs = np.concatenate([[0], np.cumsum(rcounts)])
+            pos = {g: k for k, g in enumerate(owner_order)}
+            sl = [slice(int(offs[pos[g]]), int(offs[pos[g] + 1])) for g in range(self.n)]
+            gcounts = [rcounts[pos[g]] for g in range(self.n)]
+            gdesc = torch.cat([gdesc[x] for x in sl], 0).contiguous()
+            gcoor = torch.cat([gcoor[x] for x in sl], 0).contiguous()
+        else:
+            gdesc, gcoor, gcounts = self.desc, self.coor, self.counts
+        if self.tab is not None:
+            self.e.free(self.tab)
+        self._keep = (gdesc, gcoor)
+        self.tab = self.e.table(gdesc, gcoor, gcounts)
+        self.gcounts = gcounts
+        self.my_pairs = partition_pairs(all_pairs(self.n), self.rank, self.world, gcounts if self.world > 1 else None)
+        return sum(gcounts)
+
+    def match(self, keep=True):
+        if self.mh is not None:
+            self.e.free(self.mh); self.mh = None
+        if not keep:
+            self.e.match_only(self.tab, self.my_pairs)
+            return None
+        self.mh, self.lists = self.e.match(self.tab, self.my_pairs)
+        return sum(len(m) for m in self.lists)
+
+    def seeds(self, base_seed):
+        return [(int(base_seed) + i * self.n + j) & 0xFFFFFFFF for i, j in self.my_pairs]
+
+    def ransac(self, shapes_wh, base_seed=1):
+        """shapes_wh: (w, h) per image id"""
+        self.rres = self.e.ransac(self.tab, self.mh, self.lists, self.my_pairs, shapes_wh, self.seeds(base_seed))
+        return sum(1 for r in self.rres if r["ok"])
+
+    def gather(self):
+        """-> {(i, j): (matches (M,2) <idx in i, idx in j>, ransac vector | None)}, i < j, whole job"""
+        extras = [ransac_extra(r) for r in self.rres] if getattr(self, "rres", None) is not None else None
+        if self.world > 1:
+            res = gather_match_results(self.my_pairs, self.lists, self.device, self.group, extras)
+            return {p: (v if isinstance(v, tuple) else (v, None)) for p, v in res.items()}
+        return {p: (m, extras[k] if extras else None) for k, (p, m) in enumerate(zip(self.my_pairs, self.lists))}
+
+    def close(self):
+        if self.mh is not None:
+            self.e.free(self.mh); self.mh = None
+        if self.tab is not None:
+            self.e.free(self.tab); self.tab = None

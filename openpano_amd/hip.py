@@ -313,6 +313,16 @@ class Features:
         v._owner = self
         return v
 
+    def coor_device_array(self):
+        """same for the (total, 2) float64 keypoint coordinates"""
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (int(self.total), 2), "typestr": "<f8",
+                                      "data": (int(self.coor_ptr or 0), False), "version": 2, "strides": None}
+        v._owner = self
+        return v
+
     def free(self):
         if self.handle:
             lib().op_features_free(self.handle)

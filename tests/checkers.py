@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libopenpano_ref.so")
+REF_NATIVE_SO = os.path.join(ORACLE_DIR, "_ref", "libopenpano_ref_native.so")     # the reference's own flags (oracle/Makefile)
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -303,12 +304,30 @@ def ref_available():
     return os.path.exists(REF_SO)
 
 
+def ref_native_usable():
+    """oracle/_ref/libopenpano_ref_native.so is built with -march=native of the BUILD container;
+    probe it in a subprocess (an illegal instruction must not take the caller down)."""
+    if not os.path.exists(REF_NATIVE_SO):
+        return False
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from checkers import Ref, REF_NATIVE_SO; from openpano_amd.config import PanoConfig;"
+            "r = Ref(PanoConfig(), REF_NATIVE_SO); rng = np.random.default_rng(0);"
+            "d, c = r.detect_feature(rng.random((120, 160, 3), dtype=np.float32));"
+            "m = r.match_exact(d[:40], d[:40]) if len(d) else 0; print('ok')") % (ROOT, os.path.join(ROOT, "tests"))
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
+        return p.returncode == 0 and b"ok" in p.stdout
+    except Exception:
+        return False
+
+
 class Ref(_StagedBase):
     prefix = "ref_"
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, so_path=None):
         self.cfg = cfg
-        lib = self.lib = C.CDLL(REF_SO)
+        lib = self.lib = C.CDLL(so_path or REF_SO)
         lib.ref_config_set.argtypes = [C.c_char_p, C.c_float]
         for k, v in cfg.raw_items():
             rc = lib.ref_config_set(k.encode(), float(v))

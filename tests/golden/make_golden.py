@@ -77,6 +77,7 @@ def main():
     blend_case(ref)
     ransac_case(ref, sa, sb, pairs)
     camera_case(ref)
+    natural_case(ref)
 
 
 def ransac_case(ref, sa, sb, pairs):
@@ -133,8 +134,35 @@ def camera_case(ref):
     print("camera_scene", len(shapes), "images", len(table) // 2, "pairs", int(out["cnt"].sum()) // 2, "matches; focal", out["cameras_shipped"][:, 0].round(2))
 
 
+def natural_case(ref):
+    """Natural texture: crops of the reference's published panoramas, cut by
+    tests/natural.py.  The decoded uint8 crop is stored with the reference's outputs, so the golden
+    does not depend on the JPEG decoder of the machine running the tests.  nat_match_uav.npz: the
+    exact matcher + TransformEstimation (seed injected) on the config-1 pair."""
+    import natural
+    v1 = natural.config_views(1)
+    sa = sift_case(ref, "nat_uav_a_400x600", v1[0])
+    sb = sift_case(ref, "nat_uav_b_400x600", v1[1])
+    sift_case(ref, "nat_cmu_400x600", natural.config_views(2, 3)[2])
+    sift_case(ref, "nat_uav_867x1300", natural.config_views(4, 3)[2])
+    pairs = ref.match_exact(sa.desc, sb.desc)
+    ca = (sa.coor - 0.5) * np.array([600.0, 400.0]); cb = (sb.coor - 0.5) * np.array([600.0, 400.0])
+    out = dict(pairs=pairs, coor_a=ca, coor_b=cb, shape=np.array([600, 400], np.int32))
+    for mode, cfgkv in (("homo", dict()), ("affine", dict(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1))):
+        ref.set_config(**cfgkv)
+        r = ref.ransac(pairs, ca, cb, (600, 400), (600, 400), 38)
+        out[f"{mode}_ok"] = np.int32(r["ok"]); out[f"{mode}_conf"] = np.float32(r["confidence"])
+        out[f"{mode}_homo"] = r["homo"]; out[f"{mode}_pts"] = r["inlier_pts"]
+        print("nat ransac", mode, r["ok"], r["confidence"], len(r["inlier_pts"]))
+        ref.set_config(CYLINDER=0, ESTIMATE_CAMERA=1, ORDERED_INPUT=0)
+    np.savez_compressed(os.path.join(HERE, "nat_match_uav.npz"), **out)
+    print("nat_match_uav", len(sa.desc), len(sb.desc), "->", len(pairs))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "camera":
         camera_case(Ref(PanoConfig()))
+    elif len(sys.argv) > 1 and sys.argv[1] == "natural":
+        natural_case(Ref(PanoConfig()))
     else:
         main()

@@ -60,3 +60,97 @@ def test_allgather_and_pair_partition_world2():
     assert m0 == m1 and sorted(m0) == allp
     for (i, j), v in m0.items():
         assert v == [[i * 7 + k, j * 5 + k] for k in range((i + 2 * j) % 4)]
+
+
+# ---------------------------------------------------------------------------------------------
+# The whole sharded job (openpano_amd.distributed.ShardedJob) on two gloo ranks with REAL work:
+# an oracle-backed engine runs SIFT on each rank's image shard, the features go through the same
+# bucketed all-gather the GPU path uses, each rank matches + RANSACs its share of the pair list,
+# results are gathered -- and must equal the single-rank job item by item.
+class OracleEngine:
+    """CPU stand-in for HipEngine in tests: same interface, oracle/liboracle.so underneath."""
+
+    def __init__(self, cfg):
+        from checkers import Oracle
+        self.o = Oracle(cfg)
+
+    def sift(self, images):
+        res = [self.o.detect_feature(im) for im in images]
+        counts = [len(d) for d, _ in res]
+        desc = torch.from_numpy(np.concatenate([d for d, _ in res] + [np.zeros((0, 128), np.float32)]))
+        coor = torch.from_numpy(np.concatenate([c for _, c in res] + [np.zeros((0, 2), np.float64)]))
+        return desc, coor, counts
+
+    def table(self, desc, coor, counts):
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        return [(desc[offs[i]: offs[i + 1]].numpy(), coor[offs[i]: offs[i + 1]].numpy()) for i in range(len(counts))]
+
+    def match(self, table, pairs):
+        lists = [self.o.match_exact(table[i][0], table[j][0]) for i, j in pairs]
+        return lists, lists
+
+    def ransac(self, table, mh, lists, pairs, shapes_wh, seeds):
+        return [self.o.ransac(lists[k], table[i][1], table[j][1], shapes_wh[i], shapes_wh[j], seeds[k]) for k, (i, j) in enumerate(pairs)]
+
+    def free(self, obj):
+        pass
+
+
+def _job_views():
+    from openpano_amd import synth
+    world = synth.make_world(77, 300, 900, work_scale=1600.0 / (200 + 280), density=900.0)
+    return [synth.cut_view(world, 20 + 6 * k, 20 + 110 * k, 200, 280, 70 + k) for k in range(5)]
+
+
+def _run_job(group_world):
+    from openpano_amd.config import PanoConfig
+    from openpano_amd.distributed import ShardedJob
+    views = _job_views()
+    job = ShardedJob(OracleEngine(PanoConfig()), len(views), torch.device("cpu"))
+    assert job.world == group_world
+    k_local = job.sift([views[g] for g in job.local_ids])
+    k_total = job.exchange()
+    job.match()
+    job.ransac([(280, 200)] * len(views), base_seed=9)
+    res = job.gather()
+    job.close()
+    return k_local, k_total, job.gcounts, job.my_pairs, {k: (m.tolist(), ex.tolist()) for k, (m, ex) in res.items()}
+
+
+def _job_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _run_job(world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_job_world2_equals_single_rank():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    single = _run_job(1)                     # no process group: the world-1 path of ShardedJob
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    k1, ktot1, counts1, pairs1, out1 = single
+    assert k1 == ktot1 and len(pairs1) == 10 and min(counts1) > 30
+    (_, ka, kta, ca, pa, oa), (_, kb, ktb, cb, pb, ob) = res
+    assert ka + kb == kta == ktb == ktot1                 # SIFT sharded by image, nothing lost
+    assert ca == cb == counts1                            # the exchanged table is in global image order
+    assert sorted(pa + pb) == pairs1 and not (set(pa) & set(pb))
+    assert oa == ob                                       # every rank holds the whole job after the gather
+    assert sorted(oa) == sorted(out1)
+    nok = 0
+    for p in out1:                                        # match sets, RANSAC decision / confidence / homography: identical
+        assert oa[p][0] == out1[p][0], p
+        assert np.array_equal(np.array(oa[p][1]), np.array(out1[p][1]), equal_nan=True), p
+        nok += out1[p][1][0] > 0
+    assert nok >= 3

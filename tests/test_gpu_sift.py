@@ -81,7 +81,8 @@ def test_staged_sift_bit_exact_vs_oracle(ctx, oracle, cfg, name, h, w, seed):
     _compare_stages(g, o, cfg)
 
 
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "sift_*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "sift_*.npz"))) + \
+    sorted(glob.glob(os.path.join(HERE, "golden", "nat_*x*.npz")))        # natural texture (tests/natural.py)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])

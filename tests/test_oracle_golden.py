@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sift_*.npz")))
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "sift_*.npz"))) + \
+    sorted(glob.glob(os.path.join(HERE, "golden", "nat_*x*.npz")))      # natural texture (tests/natural.py)
 
 
 def u8_to_f32(u8):
@@ -62,6 +63,27 @@ def test_exact_matcher_golden(oracle):
     # swapping the arguments swaps the pair columns (matcher.cc:21-28,68-69)
     rp = oracle.match_exact(b["desc"], a["desc"])
     assert sorted(map(tuple, rp[:, ::-1])) == sorted(map(tuple, pairs))
+
+
+def test_natural_pair_match_and_ransac_golden(oracle):
+    """config 1's natural-texture pair: exact matcher and TransformEstimation (homography and the
+    CYLINDER-mode affine) of the oracle against what the reference produced (nat_match_uav.npz)."""
+    from openpano_amd.config import PanoConfig
+    a = np.load(os.path.join(HERE, "golden", "nat_uav_a_400x600.npz"))
+    b = np.load(os.path.join(HERE, "golden", "nat_uav_b_400x600.npz"))
+    g = np.load(os.path.join(HERE, "golden", "nat_match_uav.npz"))
+    pairs = oracle.match_exact(a["desc"], b["desc"])
+    assert np.array_equal(pairs, g["pairs"]) and len(pairs) > 100
+    ca, cb = g["coor_a"], g["coor_b"]
+    assert np.array_equal(ca, (a["coor"] - 0.5) * np.array([600.0, 400.0]))
+    sh = tuple(int(v) for v in g["shape"])
+    cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+    for mode, c in (("homo", None), ("affine", cyl)):
+        r = oracle.ransac(pairs, ca, cb, sh, sh, 38, cfg=c)
+        assert bool(r["ok"]) == bool(g[mode + "_ok"]) and np.float32(r["confidence"]) == g[mode + "_conf"], mode
+        pts = np.array([[ca[pairs[k][0]][0], ca[pairs[k][0]][1], cb[pairs[k][1]][0], cb[pairs[k][1]][1]] for k in r["inliers"]])
+        assert np.array_equal(pts, g[mode + "_pts"]), mode
+        assert np.allclose(r["homo"], g[mode + "_homo"], rtol=1e-7, atol=1e-9), mode
 
 
 def test_matcher_edge_cases(oracle):
