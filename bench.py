@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native OpenPano hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--texture synthetic|natural]
+
+``--gpus N`` with N > 1 and no torch.distributed environment re-executes itself under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` (one
+process per GPU over RCCL); started by such a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 Metric (BASELINE.json): SIFT keypoints+descriptors/sec (``value``) and all-pairs matches/sec
 (``match``) on BASELINE config 4 -- 38 unordered 1300x867 images -- restated as seeded synthetic
-views (openpano_amd/synth.py; the reference's example data needs the network).
+views (openpano_amd/synth.py) or, with ``--texture natural``, as crops of the reference's published
+uav panorama (tests/natural.py).
 
-One step = one pass of the hot path over one batch: op_sift_batch over this rank's 38 images
-(inputs already resident in HBM), descriptors left in HBM.  A second timed loop measures the
-all-pairs exact match over the same descriptors (RCCL all-gather of descriptors first when N>1).
-Scaling is weak: every rank owns 38 images; the job is the unordered set of 38*N images.
+One step = one pass of the hot path over one batch: op_sift_batch over this rank's images (inputs
+already resident in HBM), descriptors left in HBM.  ``--scaling weak`` (default): every rank owns 38
+images, the job is the unordered set of 38*N images.  ``--scaling strong``: ONE 38-image job dealt
+round-robin over the N ranks (BASELINE config 4 as written).  Either way the job then runs through
+openpano_amd.distributed.ShardedJob: one bucketed RCCL all-gather of descriptors + coordinates,
+all-pairs match and RANSAC on a K_i*K_j-balanced share of the pair list, results gathered.
+``config5`` carries the strong-scaled BASELINE config 5 (128 x 4000x3000 uint8, 8128 pairs) in the
+same line; at N > 1 ``strong_config4`` carries the strong-scaled config 4 next to a weak headline.
 
 The JSON line also carries
   roofline      live HIP-event timing of the dominant kernel vs its algorithmic HBM bytes,
   cpu_baseline  the reference's CPU path (oracle/_ref when it travelled, else the C oracle) timed
-                on this box's host cores on a bounded sample of the same images (rank 0, N=1).
+                on this box's host cores on a bounded sample of the same images (rank 0, N=1),
+  parity        the timed run's descriptors and match sets compared with the oracle (rank 0, N=1),
+  protocol      SURVEY 8(d)'s protocol number: pinned host Mat32f in -> descriptors D2H out.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +40,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
-
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=38, help="config 4: images per rank (weak) / per job (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--texture", choices=("synthetic", "natural"), default="synthetic")
+    ap.add_argument("--c5-images", type=int, default=128, help="config 5 job size (128 x 4000x3000 uint8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-blend", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-4 section")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-pipeline (ESTIMATE_CAMERA) section")
+    return ap.parse_args(argv)
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one process per GPU)."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 class _StdoutToStderr:
@@ -57,6 +97,7 @@ class _StdoutToStderr:
 
 def pyramid_pixels(cfg, h, w):
     """P = sum of octave pixels for an h x w source (feature.cc:33-35, dog.cc:105-107)."""
+    import numpy as np
     ratio = np.float32(cfg.SIFT_WORKING_SIZE * 2.0) / np.float32(w + h)
     wh, ww = int(np.float32(h) * ratio), int(np.float32(w) * ratio)
     P = 0
@@ -66,42 +107,69 @@ def pyramid_pixels(cfg, h, w):
     return P, wh, ww
 
 
-def cpu_baseline(cfg, views, log):
-    """Reference CPU path on this box's host cores, bounded sample (~10-30 s of CPU work)."""
-    from checkers import Oracle, Ref, ref_available
-    cores = os.cpu_count() or 1
-    nsample = int(min(max(16, 2 * cores), 96))
-    sample = [views[i % len(views)] for i in range(nsample)]
-    kind = "port"
+def cpu_model():
     try:
-        if ref_available():
-            eng = Ref(cfg); kind = "reference"
-        else:
-            eng = Oracle(cfg)
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, views, log):
+    """Reference CPU path on this box's host cores, bounded sample.  OpenMP parallel-for over images
+    like StitcherBase::calc_feature (stitcherbase.cc:14-25); the sample holds 2 images per thread so
+    that every core is busy, the OpenMP team is warmed by an untimed call, best of 3 timed calls.
+    Build preference: the reference as shipped (-O3 -march=native, default contraction) when that
+    binary runs on this host, else the parity build (-ffp-contract=off), else the C oracle."""
+    import numpy as np
+    from checkers import Oracle, Ref, ref_available, ref_native_usable, REF_NATIVE_SO
+    cores = os.cpu_count() or 1
+    kind, flags, eng = "port", "-O3 -march=x86-64-v3 -ffp-contract=off (oracle/*.c)", None
+    try:
+        if ref_native_usable():
+            eng = Ref(cfg, REF_NATIVE_SO); kind = "reference"
+            flags = "-O3 -march=native, default -ffp-contract=fast: the reference's own flags (CMakeLists.txt:40), built in the build container"
+        elif ref_available():
+            eng = Ref(cfg); kind = "reference"; flags = "-O3 -march=x86-64-v3 -ffp-contract=off (parity build, oracle/Makefile)"
     except OSError as e:   # _ref built for another libstdc++/CPU: fall back to the C port
         log(f"oracle/_ref unusable ({e}); using the C oracle")
+    if eng is None:
         eng = Oracle(cfg)
-    eng.calc_feature_batch(sample[:2], 1)                      # warm
-    t0 = time.perf_counter(); k1 = eng.calc_feature_batch(sample[:4], 1); t1 = time.perf_counter() - t0
-    t0 = time.perf_counter(); kall = eng.calc_feature_batch(sample, cores); tall = time.perf_counter() - t0
+    nsample = int(min(2 * cores, 512))
+    threads = min(cores, nsample)
+    sample = np.ascontiguousarray(np.stack([views[i % len(views)] for i in range(nsample)]), np.float32)
+    run = (lambda a, t: eng.lib.ref_calc_feature_batch(a.reshape(-1), a.shape[0], a.shape[1], a.shape[2], t)) if kind == "reference" else \
+          (lambda a, t: eng.lib.orc_calc_feature_batch(eng._cp(), a.reshape(-1), a.shape[0], a.shape[1], a.shape[2], t))
+    run(sample[:4], 1)                                                    # page in
+    t0 = time.perf_counter(); k1 = run(sample[:4], 1); t1 = time.perf_counter() - t0
+    run(sample, threads)                                                  # warm the OpenMP team / first touch
+    best, kall = None, 0
+    for _ in range(3):
+        t0 = time.perf_counter(); kall = run(sample, threads); t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
     return {
-        "value": kall / tall, "unit": "keypoints+descriptors/s", "cores": cores, "kind": kind,
-        "sample": f"{nsample} of the workload's 1300x867 views, {'OpenMP parallel-for over images like StitcherBase::calc_feature' } with {cores} threads; "
-                  f"wall {tall:.2f} s; single-thread rate {k1 / t1:.0f}/s on 4 views",
-        "single_thread_value": k1 / t1,
+        "value": kall / best, "unit": "keypoints+descriptors/s", "cores": threads, "host_cpus": cores, "cpu_model": cpu_model(),
+        "kind": kind, "flags": flags,
+        "sample": f"{nsample} views (the workload's {len(views)} 1300x867 views repeated), OpenMP parallel-for over images like "
+                  f"StitcherBase::calc_feature with {threads} threads (2 images per thread), team warmed, best of 3: wall {best:.3f} s; "
+                  f"single-thread rate {k1 / t1:.0f}/s on 4 views",
+        "single_thread_value": k1 / t1, "ideal_scaling_of_single_thread": k1 / t1 * threads,
     }
 
 
 def match_cpu_baseline(cfg, feats, log):
-    """The reference's match loop on this box's host cores, bounded sample: the first 128 pairs of
-    the workload's pair list with (a) PairWiseMatcher as shipped (FLANN kd-forest, incl. build) and
-    (b) the exact FeatureMatcher (the parity oracle), OpenMP over pairs like stitcher.cc:106-109."""
+    """The reference's match loop on this box's host cores, bounded sample: the first 2*cores (<= all)
+    pairs of the workload's pair list with (a) PairWiseMatcher as shipped (FLANN kd-forest, incl. build)
+    and (b) the exact FeatureMatcher (the parity oracle), OpenMP over pairs like stitcher.cc:106-109."""
     from checkers import Oracle, Ref, ref_available
     cores = os.cpu_count() or 1
     n = feats.num_images
     descs = [feats.get(i)[0] for i in range(n)]
-    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)][:128]
-    out = {"cores": cores, "sample": f"first {len(pairs)} of the {n * (n - 1) // 2} pairs, OpenMP over pairs with {cores} threads"}
+    allp = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    pairs = allp[: max(128, min(len(allp), 2 * cores))]
+    out = {"cores": min(cores, len(pairs)), "sample": f"first {len(pairs)} of the {len(allp)} pairs, OpenMP over pairs with {min(cores, len(pairs))} threads, warmed, best of 2"}
     eng = None
     try:
         if ref_available():
@@ -110,27 +178,60 @@ def match_cpu_baseline(cfg, feats, log):
         log(f"oracle/_ref unusable ({e})")
     if eng is None:
         eng = Oracle(cfg); out["kind"] = "port"
-    eng.match_pairs_batch(descs, pairs[:8], cores)                  # warm
-    t0 = time.perf_counter(); m = eng.match_pairs_batch(descs, pairs, cores); t = time.perf_counter() - t0
-    out["exact_image_pairs_per_s"] = len(pairs) / t; out["exact_matches"] = int(m)
+    thr = min(cores, len(pairs))
+    eng.match_pairs_batch(descs, pairs[:thr], thr)                  # warm
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter(); m = eng.match_pairs_batch(descs, pairs, thr); t = time.perf_counter() - t0
+        best = t if best is None else min(best, t)
+    out["exact_image_pairs_per_s"] = len(pairs) / best; out["exact_matches"] = int(m)
     if out["kind"] == "reference":
-        t0 = time.perf_counter(); m2 = eng.match_pairs_batch(descs, pairs, cores, flann=True); t2 = time.perf_counter() - t0
+        t0 = time.perf_counter(); m2 = eng.match_pairs_batch(descs, pairs, thr, flann=True); t2 = time.perf_counter() - t0
         out["flann_image_pairs_per_s"] = len(pairs) / t2; out["flann_matches"] = int(m2)
     return out
 
 
-def run_ingest(hip, ctx, cfg, views, k_rank, args):
+def parity_check(hip, ctx, cfg, views, feats, log):
+    """Outside every timed region: the features the TIMED run left in HBM, and the match sets of the
+    same call bench_match times, against the CPU oracle -- every image of the workload, the first 96
+    pairs.  Bit-exact or the bench line says parity_checked: false (and the process exits 1)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from checkers import Oracle
+    orc = Oracle(cfg)
+    nt = min(64, os.cpu_count() or 1)
+    n = len(views)
+    with ThreadPoolExecutor(nt) as ex:
+        want = list(ex.map(lambda i: orc.detect_feature(views[i]), range(n)))
+    bad_img = [i for i in range(n) if not (np.array_equal(feats.get(i)[0], want[i][0]) and np.array_equal(feats.get(i)[1], want[i][1]))]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)][:96]
+    got = hip.match_pairs(ctx, cfg, feats, pairs) if hasattr(hip, "match_pairs") and pairs else []
+    with ThreadPoolExecutor(nt) as ex:
+        wantm = list(ex.map(lambda p: orc.match_exact(want[p[0]][0], want[p[1]][0]), pairs))
+    bad_pair = [p for p, g, w in zip(pairs, got, wantm) if not np.array_equal(g, w)]
+    import zlib
+    res = {"checked": True, "images": n, "descriptors": int(sum(len(w[0]) for w in want)), "images_differing": bad_img,
+           "descriptor_crc32": zlib.crc32(b"".join(np.ascontiguousarray(feats.get(i)[0]).tobytes() for i in range(n))),
+           "oracle_descriptor_crc32": zlib.crc32(b"".join(np.ascontiguousarray(w[0]).tobytes() for w in want)),
+           "pairs": len(pairs), "matches": int(sum(len(w) for w in wantm)), "pairs_differing": [list(p) for p in bad_pair],
+           "ok": not bad_img and not bad_pair}
+    if not res["ok"]:
+        log(f"PARITY FAILURE: images {bad_img}, pairs {bad_pair}")
+    return res
+
+
+def run_ingest(hip, ctx, cfg, views, dev, args):
     """SIFT over HOST-resident images (the reference hands over Mat32f in host RAM, stitcherbase.cc:16):
     every call pays the H2D copies.  fp32 Mat32f (12 B/px) vs decoder bytes (3 B/px, converted on the
-    device like read_img) -- SURVEY 8(f).1.  Reported next to `value`, never as `value`."""
+    device like read_img) -- SURVEY 8(f).1.  `protocol_*` adds the D2H of descriptors + coordinates into
+    pinned host memory: SURVEY 8(d)'s timing protocol, end to end.  Reported next to `value`, never as it."""
+    import numpy as np
+    import torch
     res = {}
     u8 = [(v * 255 + 0.5).astype(np.uint8) for v in views]
     f32 = [(v.astype(np.float64) / 255.0).astype(np.float32) for v in u8]
     for key, imgs in (("host_fp32", f32), ("host_uint8", u8)):
-        # page-locked like a decoder's output pool: ONE pinned block sliced into the images (38 separate
-        # pin_memory() calls went through PyTorch's caching host allocator, whose small-block path
-        # produced 5x slower H2D copies for the uint8 images when large device buffers had been
-        # cycled before -- an artefact of the driver program, not of the library)
+        # page-locked like a decoder's output pool: ONE pinned block sliced into the images
         stride = (imgs[0].nbytes + 255) & ~255
         block = torch.empty(stride * len(imgs), dtype=torch.uint8).pin_memory()
         flat = block.numpy()
@@ -139,15 +240,27 @@ def run_ingest(hip, ctx, cfg, views, k_rank, args):
             v = flat[k * stride: k * stride + x.nbytes].view(x.dtype).reshape(x.shape)
             v[...] = x
             pinned.append(v)
-        f = hip.sift_batch(ctx, cfg, pinned); k = int(f.total); f.free()
+        call = hip.SiftCall(ctx, cfg, pinned)
+        f = call(); k = int(f.total); f.free()
+        out_d = torch.empty((k + 1024, 128), dtype=torch.float32).pin_memory()
+        out_c = torch.empty((k + 1024, 2), dtype=torch.float64).pin_memory()
         steps = max(1, min(args.steps, 5))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps):
-            f = hip.sift_batch(ctx, cfg, pinned); f.free()
+            f = call(); f.free()
         torch.cuda.synchronize(); t = time.perf_counter() - t0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            f = call()
+            out_d[:k].copy_(torch.as_tensor(f.desc_device_array(), device=dev), non_blocking=True)
+            out_c[:k].copy_(torch.as_tensor(f.coor_device_array(), device=dev), non_blocking=True)
+            torch.cuda.synchronize()
+            f.free()
+        tp = time.perf_counter() - t0
         nbytes = sum(x.nbytes for x in imgs)
         res[key] = {"ms_per_step": t / steps * 1e3, "keypoints_per_s": k * steps / t, "h2d_bytes_per_step": nbytes,
-                    "h2d_gb_per_s_floor": nbytes * steps / t / 1e9, "descriptors": k}
+                    "h2d_gb_per_s_floor": nbytes * steps / t / 1e9, "descriptors": k,
+                    "protocol_ms_per_step": tp / steps * 1e3, "protocol_keypoints_per_s": k * steps / tp, "d2h_bytes_per_step": k * 528}
     return res
 
 
@@ -155,6 +268,8 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
     """ConnectedImages::blend of the rank's images under the homographies of a 2-row camera sweep
     (spherical projection, ESTIMATE_CAMERA mode): LinearBlender as the default config selects
     (MULTIBAND 0) and MultiBandBlender(5).  Inputs resident in HBM; the canvas stays in HBM."""
+    import numpy as np
+    import torch
     from openpano_amd.config import PanoConfig
     n = len(inputs)
     cols = -(-n // 2)
@@ -181,6 +296,7 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
         prof = {k: v[0] / steps for k, v in ctx.profile().items() if k.startswith(("blend", "multiband"))}
         ctx.set_profiling(False)
         alg = 12.0 * H * W * n + 12.0 * hw[0] * hw[1]            # every source pixel once + canvas write
+        res_roi = None
         if bcfg.MULTIBAND > 0:                                   # ... + 2*16*sum(ROI) per level (WeightedPixel planes)
             g, _, ranges = hip.blend_prepare(bcfg, [(W, H)] * n, homos, 2, n // 2)
             roi = 0
@@ -191,7 +307,7 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
             alg += 2.0 * 16 * roi * bcfg.MULTIBAND
             res_roi = roi
         kms = sum(prof.values())
-        res[key] = {"ms_per_blend": t / steps * 1e3, "canvas": [hw[0], hw[1]], "roi_pixels": (res_roi if bcfg.MULTIBAND > 0 else None), "output_mpix_per_s": hw[0] * hw[1] * steps / t / 1e6,
+        res[key] = {"ms_per_blend": t / steps * 1e3, "canvas": [hw[0], hw[1]], "roi_pixels": res_roi, "output_mpix_per_s": hw[0] * hw[1] * steps / t / 1e6,
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()},
                     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else None, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else None,
@@ -199,26 +315,51 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
     return res
 
 
+def config4_views(args, rank, world, log):
+    """-> (all views of the sets this rank needs, local image list, n_total, description)"""
+    from openpano_amd import synth
+    from openpano_amd.distributed import shard_images
+    H, W = 867, 1300
+    t0 = time.perf_counter()
+    if args.texture == "natural":
+        import natural
+        src = [natural.u8_to_f32(v) for v in natural.config_views(4)]
+        pick = lambda seed: [src[i % len(src)] for i in range(args.images)]            # noqa: E731  (one natural set exists)
+        what = "crops of the reference's published uav panorama (tests/natural.py)"
+    else:
+        pick = lambda seed: synth.image_set(args.images, H, W, seed=seed, overlap=0.45, rows=2, shuffle=True)   # noqa: E731
+        what = "seeded synthetic views (openpano_amd/synth.py)"
+    if args.scaling == "strong":
+        allv = pick(38)
+        n_total = len(allv)
+        views = [allv[g] for g in shard_images(n_total, rank, world)]
+    else:
+        views = pick(38 + 1000 * rank)               # rank r owns a seeded set of its own; the job is their union
+        n_total = len(views) * world
+    log(f"config 4 views ({what}): {len(views)} local of {n_total} in {time.perf_counter() - t0:.1f} s")
+    return views, n_total, H, W, what
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--images", type=int, default=38, help="images per rank (BASELINE config 4: 38)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-match", action="store_true")
-    ap.add_argument("--no-blend", action="store_true")
-    ap.add_argument("--no-ingest", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-pipeline (ESTIMATE_CAMERA) section")
-    args = ap.parse_args()
+    args = parse_args()
+    self_spawn(args)
+
+    import numpy as np
+    import torch  # (device memory, streams, torch.distributed: plumbing only)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    from openpano_amd import hip
+    from openpano_amd.config import PanoConfig
+    hip.Context(local_rank).close()          # no gfx950 device / no library -> fail here, loudly (no CPU fallback)
+
     dist = None
     if world > 1 or os.environ.get("OPENPANO_FORCE_DIST"):     # FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
@@ -231,19 +372,9 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-    from openpano_amd import hip, synth
-    from openpano_amd.config import PanoConfig
     cfg = PanoConfig()
-    H, W = 867, 1300
-    nimg = args.images
-    # rank r owns views [r*nimg, (r+1)*nimg) of one seeded unordered set (config 4 restated)
-    t0 = time.perf_counter()
-    views = synth.image_set(nimg, H, W, seed=38 + 1000 * rank, overlap=0.45, rows=2, shuffle=True)
-    log(f"synthetic views: {nimg} x {W}x{H} in {time.perf_counter() - t0:.1f} s")
+    views, n_total, H, W, what = config4_views(args, rank, world, log)
+    nimg = len(views)
     dev = torch.device("cuda", local_rank)
     d_imgs = [torch.from_numpy(v).to(dev) for v in views]         # inputs resident in HBM
     torch.cuda.synchronize()
@@ -296,14 +427,16 @@ def main():
         # the scan runs on the DoG layers while they are in LDS and mag/ort are never materialised)
         "build pyramid": 4 * P + 24 * P + 16 * P,
         "resize + octave grey": 12 * H * W + 4 * P,                      # source in, grey octave bases out (working image stays in LDS)
-        "sift descriptor": (k_rank / nimg) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
-        "orientation": (k_rank / nimg) * (8 * 16 * 16),
+        "sift descriptor": (k_rank / max(nimg, 1)) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
+        "orientation": (k_rank / max(nimg, 1)) * (8 * 16 * 16),
+        "orientation + descriptor": (k_rank / max(nimg, 1)) * (8 * (16 * 16 + 37 * 37) + 528),
     }
-    pmc = {}
+    pmc, pmc_src = {}, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
+            pmc_src = f"replayed from profiles/pmc_latest.json ({pmc.get('_meta', {}).get('tag', 'untagged')}; rocprofv3 --pmc passes of scripts/gpu_pmc.sh, not collected in this run)"
         except Exception:
             pmc = {}
 
@@ -311,29 +444,32 @@ def main():
         b = alg.get(name)
         dur_s = stage_ms[name] * 1e-3
         ach = (b * nimg / dur_s / 1e9) if b else None
+        tr = pmc.get(name, {}).get("hbm_bytes_per_launch") if isinstance(pmc.get(name), dict) else None
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),      # rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE) * 1024
+                "traffic": tr,      # rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE) * 1024
+                "traffic_source": pmc_src if tr is not None else None,
                 "algorithmic_bytes_per_launch": b * nimg if b else None, "avg_launch_ms": stage_ms[name]}
 
     roofline = stage_roofline(dominant) if dominant is not None else None
     stage_rooflines = {k: stage_roofline(k) for k in stage_ms if k in alg}
     # whole SIFT path against SURVEY 8(d): 12WH + 88P + G + 528K per image
-    G = (k_rank / nimg) * 8 * (16 * 16 + 37 * 37)
-    b_path = nimg * (12 * H * W + 88 * P + G + 528 * (k_rank / nimg))
+    G = (k_rank / max(nimg, 1)) * 8 * (16 * 16 + 37 * 37)
+    b_path = nimg * (12 * H * W + 88 * P + G + 528 * (k_rank / max(nimg, 1)))
     path_gbs = b_path * args.steps / t_sift / 1e9
 
+    wl = (f"BASELINE config 4 restated: {args.images} unordered {W}x{H} views per GPU (x{world} GPUs = a {n_total}-image job)" if args.scaling == "weak"
+          else f"BASELINE config 4: ONE job of {n_total} unordered {W}x{H} views dealt round-robin over {world} GPU(s)")
     out = {
         "metric": "SIFT keypoints+desc/sec and all-pairs matches/sec at 1/2/4/8 GPUs",
         "value": value, "unit": "keypoints+descriptors/s",
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": t_sift_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 4 restated: {nimg} unordered {W}x{H} views per GPU (x{args.gpus} GPUs), "
-                               "default config.cfg, inputs resident in HBM",
-                   "images_per_gpu": nimg, "image": [H, W], "keypoints_per_image": k_total / (nimg * args.gpus),
-                   "parallelism": f"images sharded {nimg}/GPU x {args.gpus}"},
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic" if args.texture == "synthetic" else "natural-texture crops (tests/golden/natural)",
+        "config": {"workload": f"{wl}; {what}; default config.cfg, inputs resident in HBM",
+                   "images_per_gpu": nimg, "images_in_job": n_total, "image": [H, W], "keypoints_per_image": k_total / max(nimg * world if args.scaling == "weak" else n_total, 1),
+                   "parallelism": f"images sharded round-robin, {nimg} on rank 0 of {world}; pair list balanced by K_i*K_j"},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "roofline": roofline,
         "stage_rooflines": stage_rooflines,
@@ -341,38 +477,55 @@ def main():
                                "frac": path_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": b_path},
     }
 
-    # ---------------- all-pairs match loop (+ RANSAC at N=1) ----------------
+    # ---------------- exchange + all-pairs match + RANSAC (ShardedJob; the same code at every N) ----------------
     args.H, args.W = H, W
     if hasattr(hip, "match_pairs") and not args.no_match:
-        from bench_match import run_match_loop
-        out["match"] = run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, log)
-        if out["match"].get("ransac") is not None:
-            out["ransac"] = out["match"].pop("ransac")
+        from bench_match import run_job_loops
+        out["match"] = run_job_loops(hip, ctx, cfg, feats, n_total, [(W, H)] * n_total, args, dist, dev, rank, world, barrier, log)
+        out["ransac"] = out["match"].pop("ransac", None)
 
     # ---------------- final warp + blend of this rank's images (N=1 only: rank 0 renders) ----------------
     if world == 1 and not args.no_blend:
         out["blend"] = run_blend(hip, ctx, cfg, inputs, H, W, args, log)
 
-    # ---------------- host-fed ingest (PCIe inclusive; never `value`) ----------------
+    # ---------------- host-fed ingest + the SURVEY 8(d) protocol number (PCIe inclusive; never `value`) ----------------
     if world == 1 and not args.no_ingest:
-        out["ingest"] = run_ingest(hip, ctx, cfg, views, k_rank, args)
+        out["ingest"] = run_ingest(hip, ctx, cfg, views, dev, args)
+        pf = out["ingest"]["host_fp32"]; pu = out["ingest"]["host_uint8"]
+        out["protocol"] = {"definition": "SURVEY 8(d) timing protocol: images in pinned host memory -> H2D -> all kernels -> D2H of descriptors + coordinates into pinned host memory",
+                           "value_mat32f": pf["protocol_keypoints_per_s"], "ms_per_step_mat32f": pf["protocol_ms_per_step"],
+                           "value_uint8": pu["protocol_keypoints_per_s"], "ms_per_step_uint8": pu["protocol_ms_per_step"],
+                           "unit": "keypoints+descriptors/s", "bound": "PCIe H2D of the source images"}
 
     # ---------------- whole Stitcher::build() on rendered rotating-camera views (N=1 only) ----------------
     if world == 1 and not args.no_e2e and not args.no_match and not args.no_blend:
         from bench_e2e import run_e2e
         out["stitch_e2e"] = run_e2e(hip, ctx, args, log)
 
-    # ---------------- CPU baseline (rank 0, N=1 only) ----------------
+    # ---------------- strong-scaled jobs in the same line: config 4 (N>1, weak headline) and config 5 ----------------
+    if not args.no_match:
+        from bench_match import run_strong_job
+        if world > 1 and args.scaling == "weak" and not args.no_strong:
+            out["strong_config4"] = run_strong_job(hip, ctx, cfg, "config4", args, dist, dev, rank, world, barrier, log)
+        if not args.no_config5:
+            out["config5"] = run_strong_job(hip, ctx, cfg, "config5", args, dist, dev, rank, world, barrier, log)
+
+    # ---------------- CPU baseline + parity of the timed run (rank 0, N=1 only) ----------------
+    rc = 0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t0 = time.perf_counter()
         with _StdoutToStderr():
+            out["parity"] = parity_check(hip, ctx, cfg, views, feats, log)
+            out["parity_checked"] = bool(out["parity"]["ok"])
             out["cpu_baseline"] = cpu_baseline(cfg, views, log)
             if out.get("match"):
                 out["match"]["cpu_baseline"] = match_cpu_baseline(cfg, feats, log)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        log(f"cpu baseline took {time.perf_counter() - t0:.1f} s")
+        rc = 0 if out["parity_checked"] else 1
+        log(f"parity + cpu baseline took {time.perf_counter() - t0:.1f} s")
     elif rank == 0:
         out["cpu_baseline"] = None
+        out["parity_checked"] = None
 
     feats.free()
     ctx.close()
@@ -381,6 +534,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -1,9 +1,10 @@
-"""All-pairs matching loop of bench.py (second metric of BASELINE.json: matches/sec).
+"""Job-level sections of bench.py: exchange + all-pairs match + RANSAC + result gather through
+openpano_amd.distributed.ShardedJob (second metric of BASELINE.json: matches/sec).
 
-N = 1: the 703 unordered pairs of this rank's 38 images.
-N > 1: descriptors are all-gathered over RCCL/xGMI (variable sizes: counts first, then padded
-payload), every rank rebuilds the global image-indexed feature table in its HBM and matches an
-interleaved 1/N share of the global unordered pair list (stitcher.cc:100 partitioned by rank).
+The same code runs at every N: at N = 1 the exchange is the identity (unless OPENPANO_FORCE_DIST=1
+initialised a one-rank RCCL group, in which case the all-gather really runs), at N > 1 features are
+all-gathered over RCCL/xGMI in one bucket and each rank matches / RANSACs a K_i*K_j-balanced share
+of the unordered pair list (stitcher.cc:100), results are all-gathered.
 """
 import time
 
@@ -11,93 +12,166 @@ import numpy as np
 import torch
 
 
-def run_match_loop(hip, ctx, cfg, feats, args, dist, dev, rank, world, barrier, log):
-    nloc = feats.num_images
-    counts = [feats.count(i) for i in range(nloc)]
-    gather_ms = None
+def _mfma_roofline(prof, flops):
+    """forward sweep (every row of the smaller set) + reverse strip (survivors only), both including
+    their exact re-score epilogues; algorithmic work = 2*128*Ki*Kj flop per unordered pair"""
+    mfma_ms = (prof.get("matcher mfma forward") or 0.0) + (prof.get("matcher mfma reverse") or 0.0)
+    if not mfma_ms:
+        return None
+    # the sweeps rank with a two-term bf16 split: three v_mfma_f32_32x32x16_bf16 per 16 elements, i.e.
+    # 3x the algorithmic flop are executed on the bf16 matrix pipe (dense peak ~2.5 PFLOP/s,
+    # MI355X_MICROARCH.md); the fp32-MFMA figure of SURVEY 8(d) is kept next to it for comparison
+    alg = flops / (mfma_ms * 1e-3) / 1e12             # this rank's share, this rank's kernel time
+    return {"kernel": "matcher mfma forward + reverse", "bound": "mfma", "achieved": 3.0 * alg, "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": 3.0 * alg / 2500.0, "traffic": None,
+            "dtype": "bf16 x3 split, fp32 accumulate; exact fp32 re-score decides",
+            "algorithmic_tflops": alg, "algorithmic_over_fp32_mfma_peak": alg / 157.3,
+            "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms}
+
+
+def _reduce(dist, dev, tmax_vals, sum_vals):
+    t = torch.tensor(tmax_vals, dtype=torch.float64, device=dev)
+    s = torch.tensor(sum_vals, dtype=torch.float64, device=dev)
     if dist is not None:
-        from openpano_amd.distributed import allgather_descriptors
-        total = int(feats.total)
-        # zero-copy torch view of the library-owned descriptor buffer (same HIP runtime)
-        dloc = torch.as_tensor(feats.desc_device_array(), device=dev) if total else torch.zeros((0, 128), device=dev)
-        allgather_descriptors(dloc, counts)                              # warm-up (RCCL init)
-        barrier()
-        t0 = time.perf_counter()
-        glob, all_counts = allgather_descriptors(dloc, counts)
-        barrier()
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        gfeats = hip.Features.from_device(ctx, glob.data_ptr(), all_counts)
-        nglob = len(all_counts)
-    else:
-        gfeats = feats
-        nglob = nloc
-        all_counts = counts
-    pairs = [(i, j) for i in range(nglob) for j in range(i + 1, nglob)]
-    from openpano_amd.distributed import partition_pairs
-    mine = partition_pairs(pairs, rank, world, all_counts if dist is not None else None)
-    flops = sum(2.0 * 128 * all_counts[i] * all_counts[j] for i, j in mine)
-    m = hip.match_pairs(ctx, cfg, gfeats, mine)                      # warm-up (and the match count)
-    nmatch = sum(len(x) for x in m)
-    gather_results_ms = None
-    if dist is not None:                                             # results to every rank (rank 0 runs the host stages)
-        from openpano_amd.distributed import gather_match_results
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t], [float(x) for x in s]
+
+
+def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, world, barrier, log):
+    """Timed loops over the features the SIFT loop of bench.py left in HBM."""
+    from openpano_amd.distributed import HipEngine, ShardedJob
+    eng = HipEngine(ctx, cfg, dev)
+    job = ShardedJob(eng, n_total, dev)
+    job.adopt(feats)
+    gather_ms = None
+    job.exchange()                                                   # warm-up (RCCL init, allocation)
+    if dist is not None:
         barrier(); t0 = time.perf_counter()
-        allm = gather_match_results(mine, m, dev)
-        barrier(); gather_results_ms = (time.perf_counter() - t0) * 1e3
-        assert len(allm) == len(pairs)
+        job.exchange()
+        barrier(); gather_ms = (time.perf_counter() - t0) * 1e3
+    mine = job.my_pairs
+    flops = sum(2.0 * 128 * job.gcounts[i] * job.gcounts[j] for i, j in mine)
+    nmatch = job.match()                                             # warm-up, and the lists RANSAC consumes
     ctx.set_profiling(True); ctx.profile_reset()
     steps = max(1, min(args.steps, 10))
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        mh = hip.match_pairs_handle(ctx, cfg, gfeats, mine)         # results stay in the op_matches handle
-        mh.free()
+        eng.match_only(job.tab, mine)                                # results stay in the op_matches handle
     barrier()
     t = time.perf_counter() - t0
     prof = {k: v[0] / steps for k, v in ctx.profile().items() if k.startswith("matcher")}
     ctx.set_profiling(False)
-    tt = torch.tensor([t], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(len(mine)), float(nmatch), flops], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    tmax = float(tt[0]); npairs, nm, fl = (float(x) for x in agg)
-    # forward sweep (every row of the smaller set) + reverse strip (survivors only), both including
-    # their exact re-score epilogues; algorithmic work = 2*128*Ki*Kj flop per unordered pair
-    mfma_ms = (prof.get("matcher mfma forward") or 0.0) + (prof.get("matcher mfma reverse") or 0.0)
+    (tmax,), (npairs, nm, fl) = _reduce(dist, dev, [t], [float(len(mine)), float(nmatch), flops])
     res = {
         "image_pairs_per_s": npairs * steps / tmax, "matches_per_s": nm * steps / tmax,
         "image_pairs": int(npairs), "matches": int(nm), "steps": steps, "ms_per_step": tmax / steps * 1e3,
-        "descriptor_allgather_ms": gather_ms, "match_results_gather_ms": gather_results_ms, "stage_ms": {k: round(v, 4) for k, v in prof.items()},
-        "roofline": None,
+        "descriptor_allgather_ms": gather_ms, "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None,
+        "stage_ms": {k: round(v, 4) for k, v in prof.items()},
+        "roofline": _mfma_roofline(prof, flops),
     }
-    if mfma_ms:
-        # the sweeps rank with a two-term bf16 split: three v_mfma_f32_32x32x16_bf16 per 16 elements, i.e.
-        # 3x the algorithmic flop are executed on the bf16 matrix pipe (dense peak ~2.5 PFLOP/s,
-        # MI355X_MICROARCH.md); the fp32-MFMA figure of SURVEY 8(d) is kept next to it for comparison
-        alg = flops / (mfma_ms * 1e-3) / 1e12             # this rank's share, this rank's kernel time
-        res["roofline"] = {"kernel": "matcher mfma forward + reverse", "bound": "mfma", "achieved": 3.0 * alg, "peak": 2500.0,
-                           "unit": "TFLOP/s", "frac": 3.0 * alg / 2500.0, "traffic": None,
-                           "dtype": "bf16 x3 split, fp32 accumulate; exact fp32 re-score decides",
-                           "algorithmic_tflops": alg, "algorithmic_over_fp32_mfma_peak": alg / 157.3,
-                           "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms}
-    # ---- RANSAC over the same pairs (batched TransformEstimation::get_transform + acceptance) ----
-    if world == 1:
-        shapes = [(args.W, args.H)] * nglob
-        mh = hip.match_pairs_handle(ctx, cfg, gfeats, mine)
-        ok, inl = hip.ransac_pairs_summary(ctx, cfg, gfeats, mh, mine, shapes, base_seed=1)     # warm-up
-        rsteps = max(1, min(args.steps, 5))
-        ctx.set_profiling(True); ctx.profile_reset()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(rsteps):
-            hip.ransac_pairs_summary(ctx, cfg, gfeats, mh, mine, shapes, base_seed=1)
-        torch.cuda.synchronize(); tr = time.perf_counter() - t0
-        rprof = {k: v[0] / rsteps for k, v in ctx.profile().items() if k.startswith("ransac")}
-        ctx.set_profiling(False)
-        mh.free()
-        res["ransac"] = {"image_pairs_per_s": len(mine) * rsteps / tr, "ms_per_step": tr / rsteps * 1e3, "pairs": len(mine),
-                         "accepted_pairs": ok, "inliers": inl, "iterations": cfg.RANSAC_ITERATIONS,
-                         "stage_ms": {k: round(v, 4) for k, v in rprof.items()}}
-    if gfeats is not feats:
-        gfeats.free()
+    # ---- RANSAC over this rank's pairs (batched TransformEstimation::get_transform + acceptance) ----
+    seeds = job.seeds(1)
+    ok, inl = eng.ransac_summary(job.tab, job.mh, mine, shapes, seeds)                     # warm-up
+    rsteps = max(1, min(args.steps, 5))
+    ctx.set_profiling(True); ctx.profile_reset()
+    barrier(); t0 = time.perf_counter()
+    for _ in range(rsteps):
+        eng.ransac_summary(job.tab, job.mh, mine, shapes, seeds)
+    barrier(); tr = time.perf_counter() - t0
+    rprof = {k: v[0] / rsteps for k, v in ctx.profile().items() if k.startswith("ransac")}
+    ctx.set_profiling(False)
+    (trmax,), (okt, inlt) = _reduce(dist, dev, [tr], [float(ok), float(inl)])
+    res["ransac"] = {"image_pairs_per_s": npairs * rsteps / trmax, "ms_per_step": trmax / rsteps * 1e3, "pairs": int(npairs),
+                     "accepted_pairs": int(okt), "inliers": int(inlt), "iterations": cfg.RANSAC_ITERATIONS,
+                     "stage_ms": {k: round(v, 4) for k, v in rprof.items()}}
+    # ---- results (match lists + RANSAC vectors) to every rank: rank 0 runs the host stages ----
+    if dist is not None:
+        job.ransac(shapes, 1)
+        barrier(); t0 = time.perf_counter()
+        allres = job.gather()
+        barrier(); res["match_results_gather_ms"] = (time.perf_counter() - t0) * 1e3
+        assert len(allres) == n_total * (n_total - 1) // 2
+    else:
+        res["match_results_gather_ms"] = None
+    job.close()
+    return res
+
+
+def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, log):
+    """ONE job dealt over the N ranks (strong scaling), one warm pass + one timed pass with a barrier
+    between phases: SIFT on the local shard, feature all-gather, match + RANSAC on this rank's share
+    of the pair list, result gather.
+      config4: BASELINE config 4, the 38 seeded 1300x867 views (fp32, as bench.py's headline)
+      config5: BASELINE config 5, 128 synthetic 4000x3000 uint8 images, 8128 pairs (MFMA stress)"""
+    from openpano_amd import synth
+    from openpano_amd.distributed import HipEngine, ShardedJob, shard_images
+    t0 = time.perf_counter()
+    if kind == "config4":
+        n, H, W = 38, 867, 1300
+        allv = synth.image_set(n, H, W, seed=38, overlap=0.45, rows=2, shuffle=True)
+        ids = shard_images(n, rank, world)
+        d_imgs = [torch.from_numpy(allv[g]).to(dev) for g in ids]
+        inputs = [(t.data_ptr(), H, W) for t in d_imgs]
+        what = "38 unordered 1300x867 fp32 views (seed 38)"
+    else:
+        n, H, W = args.c5_images, 3000, 4000
+        ids = shard_images(n, rank, world)
+        d_imgs = synth.config5_views(ids, dev)
+        inputs = [(t.data_ptr(), H, W, "u8") for t in d_imgs]
+        what = f"{n} synthetic 4000x3000 uint8 images, groups of 8 share a texture (openpano_amd/synth.py config5_views)"
+    torch.cuda.synchronize()
+    log(f"strong {kind}: {len(ids)} local of {n} images generated in {time.perf_counter() - t0:.1f} s")
+    eng = HipEngine(ctx, cfg, dev)
+    job = ShardedJob(eng, n, dev)
+    shapes = [(W, H)] * n
+    call = hip.SiftCall(ctx, cfg, inputs) if inputs else None
+    sift_in = (lambda: call()) if call is not None else []
+
+    def one_pass(timed):
+        ph = {}
+
+        def lap(name, fn):
+            barrier(); t = time.perf_counter(); r = fn(); barrier(); ph[name] = (time.perf_counter() - t) * 1e3
+            return r
+        k = lap("sift", lambda: job.sift(sift_in))
+        lap("feature all-gather", job.exchange)
+        if timed:
+            ctx.set_profiling(True); ctx.profile_reset()
+        nm = lap("match", job.match)
+        prof = {}
+        if timed:
+            prof = {kk: v[0] for kk, v in ctx.profile().items() if kk.startswith("matcher")}
+            ctx.set_profiling(False)
+        seeds = job.seeds(1)
+        ok, inl = lap("ransac", lambda: eng.ransac_summary(job.tab, job.mh, job.my_pairs, shapes, seeds))
+        if dist is not None:
+            job.rres = None
+            lap("result gather", job.gather)
+        return ph, k, nm, ok, inl, prof
+
+    one_pass(False)                                   # warm (allocation pool, RCCL, kernels)
+    barrier(); t0 = time.perf_counter()
+    ph, k, nm, ok, inl, prof = one_pass(True)
+    wall = (time.perf_counter() - t0) * 1e3
+    mine = job.my_pairs
+    flops = sum(2.0 * 128 * job.gcounts[i] * job.gcounts[j] for i, j in mine)
+    names = list(ph)
+    tm, sm = _reduce(dist, dev, [ph[x] for x in names] + [wall], [float(k), float(len(mine)), float(nm), float(ok), float(inl), flops])
+    phm = dict(zip(names, tm[:-1]))
+    res = {"workload": f"{what}; ONE job dealt round-robin over {world} GPU(s); inputs resident in HBM", "scaling": "strong",
+           "images": n, "image": [H, W], "n_gpus": world, "descriptors": int(sm[0]), "keypoints_per_image": sm[0] / n,
+           "image_pairs": int(sm[1]), "matches": int(sm[2]), "accepted_pairs": int(sm[3]), "inliers": int(sm[4]),
+           "phase_ms": {x: round(v, 4) for x, v in phm.items()}, "job_wall_ms": tm[-1],
+           "keypoints_per_s": sm[0] / (phm["sift"] * 1e-3), "image_pairs_per_s": sm[1] / (phm["match"] * 1e-3),
+           "matches_per_s": sm[2] / (phm["match"] * 1e-3), "ransac_image_pairs_per_s": sm[1] / (phm["ransac"] * 1e-3),
+           "match_stage_ms": {x: round(v, 4) for x, v in prof.items()},
+           "match_roofline": _mfma_roofline(prof, flops),
+           "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
+    job.close()
+    if eng._feats is not None:
+        eng._feats.free(); eng._feats = None
+    del d_imgs
+    torch.cuda.empty_cache()
     return res

@@ -3,7 +3,7 @@
  *
  * The reference has no FFI: its seam is the C++ class surface.  Each entry point below names
  * the reference interface it stands in for (file:line under /root/reference/src); the C++
- * adapters in openpano_amd/csrc/adapters/ re-expose the reference's own class names
+ * adapters in openpano_amd/host/pano_hip.hh re-expose the reference's own class names
  * (FeatureDetector::detect_feature, PairWiseMatcher::match, ...) on top of these calls, and
  * INTEGRATION.md shows the binding a maintainer would add to the reference tree.
  *
@@ -151,6 +151,11 @@ int op_sift_dump_desc(const op_sift_dump* d, float* desc, double* coor);    /* c
  * evaluated on the GPU over n host values (tests: device == reference libm, bit for bit).
  * which: 0 expf(x), 1 cosf(x), 2 sinf(x), 3 hypotf(x,y), 4 fast_atan(y,x)+pi */
 int op_debug_math(op_ctx* ctx, int which, const float* x, const float* y, int n, float* out);
+/* Per-image capacity of the context's raw / refined candidate lists (default 16384).  The lists
+ * are speculative: a batch that outgrows them re-runs once with the observed size and the context
+ * keeps the larger capacity (the reference appends to std::vectors, extrema.cc:36-61).  Exposed so
+ * that tests can force the overflow path with a tiny capacity; >= 64. */
+int op_debug_set_raw_capacity(op_ctx* ctx, int cap);
 
 /* =====================================================================================
  * MATCH -- replaces PairWiseMatcher (feature/matcher.hh:40-67, matcher.cc:73-135) as used by

@@ -30,6 +30,7 @@ struct op_matches {
 };
 
 const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p) { return m->pairs[p]; }
+int op_matches_num_pairs(const op_matches* m) { return m->npairs; }
 
 namespace {
 
@@ -469,10 +470,12 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t arena_bytes = o_up + al(up_bytes);
 	char* arena = nullptr;
 	const size_t hml_bytes = al(sizeof(int) * (1 + 3 * nres));
-	char* pin = (char*)ctx->pinned_scratch(hml_bytes + up_bytes);          // pinned: copies run at link rate, asynchronously
+	char* pin = (char*)ctx->pinned_scratch(hml_bytes + al(up_bytes) + 256);   // pinned: copies run at link rate, asynchronously
 	int rc = OP_OK;
 	if (!pin) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
 	int* h_ml = (int*)pin;
+	int* h_slow = (int*)(pin + hml_bytes + al(up_bytes));                  // slow_fwd_n, slow_rev_n of this call
+	h_slow[0] = h_slow[1] = 0;
 	std::memcpy(pin + hml_bytes, pds.data(), sizeof(PairDesc) * npairs);
 	if (!work.empty()) std::memcpy(pin + hml_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
@@ -520,7 +523,15 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	hs.reset(); hs.reset(new HostScope(ctx, "matcher wait + result copy (host)"));
 	if (!work.empty()) {
 		MCHK(hipMemcpyAsync(h_ml, d_mlist, sizeof(int) * (1 + 3 * kHead), hipMemcpyDeviceToHost, st));
+		MCHK(hipMemcpyAsync(h_slow, (int*)(arena + o_ctrl) + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
 		MCHK(hipStreamSynchronize(st));
+		if (h_slow[0] > slow_cap || h_slow[1] > slow_cap) {
+			// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
+			// descriptors in one call): the rows beyond the queue were not matched -- never return that as OP_OK
+			op_set_error("op_match_pairs: exact-scan queue overflow (" + std::to_string(std::max(h_slow[0], h_slow[1])) + " rows > " +
+					std::to_string(slow_cap) + "); split the pair list");
+			rc = OP_ERR_CAPACITY; goto done;
+		}
 		if ((size_t)h_ml[0] > kHead) {
 			MCHK(hipMemcpyAsync(h_ml + 1 + 3 * kHead, d_mlist + 1 + 3 * kHead, sizeof(int) * 3 * ((size_t)h_ml[0] - kHead), hipMemcpyDeviceToHost, st));
 			MCHK(hipStreamSynchronize(st));

@@ -29,6 +29,7 @@ FeatView op_features_view(const op_features* f);
 const double* op_features_coor_device(const op_features* f);
 struct op_matches;
 const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p);
+int op_matches_num_pairs(const op_matches* m);
 
 using opransac::P2;
 
@@ -359,6 +360,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	op_ransac_result* R = new op_ransac_result;
 	R->items.resize(npairs);
 	if (npairs == 0) { *out = R; return OP_OK; }
+	if (op_matches_num_pairs(mt) != npairs) { delete R; OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: op_matches holds a different number of pairs than the pair list"); }
 	const bool affine = cfg->CYLINDER || cfg->TRANS;                    // transform_estimate.cc:34-37
 	const int nsample = (affine ? 6 : 8) / 2 + 4;                       // :53
 	const int iters = cfg->RANSAC_ITERATIONS;
@@ -383,6 +385,13 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		h.kp2 = coor.data() + fv.offsets[j] * 2; h.nk2 = fv.counts[j];
 		h.s1 = Shape{shapes_wh[2 * i], shapes_wh[2 * i + 1]}; h.s2 = Shape{shapes_wh[2 * j], shapes_wh[2 * j + 1]};
 		if (h.m > 65535) { delete R; OP_FAIL(OP_ERR_CAPACITY, "more than 65535 matches in one pair"); }
+		// the match lists may come from the public op_matches_from_host or from another op_features:
+		// an index outside the image's keypoints would be a host heap read out of bounds below
+		for (int k = 0; k < h.m; ++k)
+			if ((unsigned)h.match[2 * k] >= (unsigned)h.nk1 || (unsigned)h.match[2 * k + 1] >= (unsigned)h.nk2) {
+				delete R;
+				OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: pair " + std::to_string(p) + " match " + std::to_string(k) + " indexes a keypoint outside its image");
+			}
 		// ransac_inlier_thres (float) and INLIER_DIST = sqr(float) (transform_estimate.cc:46,133)
 		const float thres = (float)((h.s1.w + h.s1.h) * 0.5 / 800 * cfg->RANSAC_INLIER_THRES);
 		const float inlier_dist = thres * thres;

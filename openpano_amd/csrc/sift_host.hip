@@ -35,6 +35,7 @@ struct Workspace {
 	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, offsets, oriented;
 	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch for counts/offsets
 	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
+	int raw_cap = 16384;                             // per-image capacity of the raw / refined lists; grows on overflow (run_group)
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
 		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); offsets.release(); oriented.release();
@@ -92,8 +93,6 @@ struct op_sift_dump {
 };
 
 namespace {
-
-constexpr int kCap = 16384;            // per-image capacity of raw / refined keypoint lists
 
 // feature/gaussian.cc:17-40 (GaussCache) + gaussian.hh:96-103 (sigma bank), host side
 int build_gauss_bank(const op_config& cfg, SiftPlan& p) {
@@ -198,7 +197,11 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	int rc = build_plan(cfg, n, sh, sw, plan);
 	if (rc != OP_OK) return rc;
 	hipStream_t st = ctx->stream;
-	const int cap = kCap;
+	// per-image capacity of the raw / refined lists: speculative like capK below.  The kernels clamp
+	// their writes and keep counting; a batch whose densest image outgrew the capacity grows the
+	// buffers to the observed maximum and re-runs once (the reference has no such limit:
+	// extrema.cc:36-61 appends to std::vectors).  The capacity sticks to the context.
+	const int cap = W.raw_cap;
 
 	// --- buffers
 	HIPCHK(W.ws.ensure(sizeof(float) * (size_t)plan.ws_stride * n));
@@ -288,9 +291,16 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	std::vector<int> raw_count(h_counts, h_counts + n), refined_count(h_counts + n, h_counts + 2 * n);
 	res.counts.assign(h_counts + 2 * n, h_counts + 3 * n);
 	res.total = total;
-	for (int i = 0; i < n; ++i)
-		if (raw_count[i] > cap)
-			OP_FAIL(OP_ERR_CAPACITY, "raw extrema list overflow: " + std::to_string(raw_count[i]) + " > " + std::to_string(cap));
+	{
+		int mx = 0;
+		for (int i = 0; i < n; ++i) mx = std::max(mx, raw_count[i]);
+		if (mx > cap) {
+			if (mx > (1 << 26)) OP_FAIL(OP_ERR_CAPACITY, "raw extrema list overflow: " + std::to_string(mx));
+			pool_free(res.desc); pool_free(res.coor); pool_free(res.real); res.desc = nullptr; res.coor = nullptr; res.real = nullptr;
+			W.raw_cap = mx + mx / 4 + 64;          // counts are deterministic: the re-run cannot overflow again
+			return run_group(ctx, cfg, imgs, W, plan, res, keep);
+		}
+	}
 
 	if (keep) {
 		keep->cap = cap;
@@ -369,6 +379,12 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 		for (auto& r : results) { pool_free(r.desc); pool_free(r.coor); pool_free(r.real); }
 	}
 	*out = f;
+	return OP_OK;
+}
+
+int op_debug_set_raw_capacity(op_ctx* ctx, int cap) {
+	if (!ctx || cap < 64) OP_FAIL(OP_ERR_INVALID, "op_debug_set_raw_capacity: bad argument");
+	ctx_workspace(ctx)->raw_cap = cap;
 	return OP_OK;
 }
 

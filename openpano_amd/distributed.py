@@ -180,6 +180,10 @@ class HipEngine:
     def ransac(self, table, mh, lists, pairs, shapes_wh, seeds):
         return self.hip.ransac_pairs(self.ctx, self.cfg, table, mh, pairs, shapes_wh, seeds=seeds)
 
+    def ransac_summary(self, table, mh, pairs, shapes_wh, seeds):
+        """op_ransac_pairs without unpacking every pair into Python -> (accepted pairs, inliers)"""
+        return self.hip.ransac_pairs_summary(self.ctx, self.cfg, table, mh, pairs, shapes_wh, seeds=seeds)
+
     def free(self, obj):
         obj.free()
 
@@ -218,8 +222,17 @@ class ShardedJob:
         self.desc, self.coor, self.counts = self.e.sift(local_images)
         return sum(self.counts)
 
+    def adopt(self, feats):
+        """use an existing op_features of this rank's shard (HipEngine only; zero-copy views)"""
+        self.counts = [feats.count(i) for i in range(feats.num_images)]
+        assert len(self.counts) == len(self.local_ids)
+        self.desc = torch.as_tensor(feats.desc_device_array(), device=self.device) if int(feats.total) else torch.zeros((0, 128), device=self.device)
+        self.coor = torch.as_tensor(feats.coor_device_array(), device=self.device) if int(feats.total) else torch.zeros((0, 2), dtype=torch.float64, device=self.device)
+        self._adopted = feats
+        return sum(self.counts)
+
     def exchange(self):
-        if self.world > 1:
+        if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the collective really runs
             gdesc, gcoor, rcounts, nimg = allgather_features(self.desc, self.coor, self.counts, self.group)
             owner_order = [g for r in range(self.world) for g in shard_images(self.n, r, self.world)]
             assert [len(shard_images(self.n, r, self.world)) for r in range(self.world)] == nimg

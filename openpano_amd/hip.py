@@ -137,6 +137,7 @@ def lib():
     L.op_sift_dump_kp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_sift_dump_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.op_debug_set_raw_capacity.argtypes = [C.c_void_p, C.c_int]
     if hasattr(L, "op_match_pairs"):
         L.op_match_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.op_matches_count.argtypes = [C.c_void_p, C.c_int]
@@ -203,6 +204,10 @@ class Context:
             check(lib().op_ctx_profile_get(self.handle, i, C.byref(lab), C.byref(ms), C.byref(calls)))
             out[lab.value.decode()] = (ms.value, calls.value)
         return out
+
+    def set_raw_capacity(self, cap: int):
+        """test hook: per-image capacity of the speculative raw / refined lists (op_debug_set_raw_capacity)"""
+        check(lib().op_debug_set_raw_capacity(self.handle, int(cap)))
 
     def close(self):
         if self.handle:
@@ -508,15 +513,17 @@ def ransac_pairs(ctx: Context, cfg, feats: Features, matches: Matches, pairs, sh
     return out
 
 
-def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0):
+def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0, seeds=None):
     """op_ransac_pairs without unpacking every pair into Python: -> (accepted pairs, total inliers)."""
     L = lib()
     pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
     sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+    sd = np.ascontiguousarray(np.asarray(seeds, np.uint32)) if seeds is not None else None
     ccfg = OpConfig.from_config(cfg)
     h = C.c_void_p()
     check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
-                            sh.ctypes.data_as(C.c_void_p), None, int(base_seed), C.byref(h)))
+                            sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
+                            int(base_seed), C.byref(h)))
     ok = 0; inl = 0
     for p in range(len(pr)):
         if L.op_ransac_ok(h, p):

@@ -55,10 +55,18 @@ for k, cs in acc.items():
     lab = LABELS.get(k)
     if lab and lab not in out:
         out[lab] = e
+out["_meta"] = {"tag": tag, "collected_by": "scripts/gpu_pmc.sh (rocprofv3 --kernel-trace --pmc, one counter set per pass)",
+                "lib_sha256_16": None}
+try:
+    import hashlib
+    lib = os.path.join(os.path.dirname(root), "openpano_amd", "libopenpano_hip.so")
+    out["_meta"]["lib_sha256_16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+except OSError:
+    pass
 path = os.path.join(root, f"{tag}_pmc.json")
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 for k in sorted(out):
-    if k.startswith("k_"):
+    if k.startswith("k_") and isinstance(out[k], dict):
         e = out[k]
         print(f"{k:22s} hbm/launch {e.get('hbm_bytes_per_launch', float('nan')) / 1e6:10.2f} MB  "
               f"VALU insts {e.get('SQ_INSTS_VALU', float('nan')):.3g}  LDS insts {e.get('SQ_INSTS_LDS', float('nan')):.3g}  "

@@ -1,45 +1,57 @@
-"""CPU: the bench line committed under profiles/ obeys the driver's contract (one JSON object with
-the agreed keys, a consistent roofline and CPU baseline) and bench.py parses / declares its flags."""
-import glob
-import json
+"""CPU: bench.py's own logic (not a committed output): the CLI flags of the driver contract, the
+self-launch of N ranks, the algorithmic-byte bookkeeping, and the CPU-baseline / parity legs on a
+tiny sample."""
 import os
-import re
 import subprocess
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _latest():
-    fs = glob.glob(os.path.join(ROOT, "profiles", "r*_bench_v*.json"))
-    assert fs, "no committed bench line under profiles/"
-    return max(fs, key=lambda f: (int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), int(re.search(r"_v(\d+)", f).group(1))))
-
-
-def test_committed_bench_line_obeys_contract():
-    d = json.load(open(_latest()))
-    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert d["metric"] == base["metric"] and d["unit"] and d["higher_is_better"] is True
-    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
-    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
-    # achieved = algorithmic bytes / live kernel time
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["unit"] == d["unit"]
-    # value = descriptors of the batch / time per batch
-    k = d["config"]["keypoints_per_image"] * d["config"]["images_per_gpu"]
-    assert abs(d["value"] - k / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["value"] > 30 * c["value"]                      # >= 30x the reference CPU on config 4
+sys.path.insert(0, ROOT)
 
 
 def test_bench_cli_declares_the_contract_flags():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup"):
+    for flag in ("--gpus", "--steps", "--warmup", "--scaling"):
         assert flag in out.stdout
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` must become the launcher (one process per GPU).  Without a GPU each
+    rank gets as far as op_ctx_create and fails THERE -- loudly, no CPU fallback -- not at a
+    'use torch.distributed.run' SystemExit."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the spawned ranks would run the whole bench")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0
+    assert "spawning 2 ranks" in out.stderr
+    assert out.stderr.count("op_ctx_create: no HIP device available") >= 2, out.stderr[-2000:]
+    assert "launch multi-GPU runs with" not in out.stderr
+
+
+def test_pyramid_pixels_matches_the_oracle_plan(oracle, cfg):
+    import bench
+    for h, w in ((867, 1300), (400, 600), (3000, 4000)):
+        P, wh, ww = bench.pyramid_pixels(cfg, h, w)
+        st = oracle.sift_stages(np.zeros((h, w, 3), np.float32), planes=False)
+        assert (wh, ww) == st.dims[0]
+        assert P == sum(a * b for a, b in st.dims)
+
+
+def test_cpu_baseline_leg_runs_and_reports_what_it_did(cfg):
+    """the cpu_baseline leg on a tiny sample: threads capped at the sample size, warmed, best-of-3"""
+    import bench
+    from openpano_amd import synth
+    world = synth.make_world(3, 260, 400, work_scale=1600.0 / (200 + 280), density=900.0)
+    views = [synth.cut_view(world, 20, 20 + 30 * k, 200, 280, k) for k in range(3)]
+    with bench._StdoutToStderr():
+        r = bench.cpu_baseline(cfg, views, lambda m: None)
+    assert r["kind"] in ("reference", "port") and r["value"] > 0 and r["single_thread_value"] > 0
+    assert 1 <= r["cores"] <= (os.cpu_count() or 1) and r["cores"] <= 2 * (os.cpu_count() or 1)
+    assert r["cpu_model"] and "best of 3" in r["sample"] and r["flags"]

@@ -89,3 +89,18 @@ def test_ransac_golden_fixture(ctx, cfg):
         mh.free(); f.free()
         return r
     _ransac_golden_check(run, g)
+
+
+def test_ransac_rejects_foreign_match_indices(ctx, cfg):
+    """match lists can come from op_matches_from_host / another op_features; an index
+    outside the image's keypoints is OP_ERR_INVALID, not a host heap read out of bounds."""
+    from openpano_amd import hip
+    ca = np.random.default_rng(0).random((20, 2)) * 100
+    f = hip.Features.from_host(ctx, [np.zeros((20, 128), np.float32), np.zeros((10, 128), np.float32)], [ca, ca[:10]])
+    bad = hip.Matches.from_host([np.array([[0, 0], [19, 10]], np.int32)])          # second index: 10 >= counts[1]
+    with pytest.raises(hip.OpenPanoHipError):
+        hip.ransac_pairs(ctx, cfg, f, bad, [(0, 1)], [(100, 100)] * 2, seeds=[1])
+    two = hip.Matches.from_host([np.zeros((0, 2), np.int32)] * 2)
+    with pytest.raises(hip.OpenPanoHipError):                                      # op_matches of 2 pairs, pair list of 1
+        hip.ransac_pairs(ctx, cfg, f, two, [(0, 1)], [(100, 100)] * 2, seeds=[1])
+    bad.free(); two.free(); f.free()

@@ -232,3 +232,34 @@ def test_concurrent_contexts(oracle, cfg):
     assert not errors, errors
     for k in range(8):
         assert np.array_equal(results[k][0], want[k][0]) and np.array_equal(results[k][1], want[k][1]), k
+
+
+def test_raw_capacity_overflow_reruns_instead_of_failing(oracle, cfg):
+    """The raw / refined candidate lists are speculative: with a capacity far below the
+    image's candidate count the batch re-runs once with the observed size -- same features, no
+    OP_ERR_CAPACITY -- and the context keeps the grown capacity."""
+    from openpano_amd import hip
+    c = hip.Context(0)
+    try:
+        c.set_raw_capacity(64)
+        imgs = [_view(400, 600, 1), _view(400, 600, 3)]
+        f = hip.sift_batch(c, cfg, imgs)
+        for i, im in enumerate(imgs):
+            d, co = f.get(i)
+            od, oc = oracle.detect_feature(im)
+            assert len(d) > 300 and np.array_equal(d, od) and np.array_equal(co, oc), i
+        f.free()
+        f = hip.sift_batch(c, cfg, imgs[::-1])            # steady state after the growth
+        assert np.array_equal(f.get(1)[0], oracle.detect_feature(imgs[0])[0])
+        f.free()
+        # a lowered PRE_COLOR_THRES (more raw candidates, same survivors' arithmetic) through the same path
+        from openpano_amd.config import PanoConfig
+        c.set_raw_capacity(64)
+        loose = PanoConfig(PRE_COLOR_THRES=0.01)
+        from checkers import Oracle
+        f = hip.sift_batch(c, loose, imgs[:1])
+        od, oc = Oracle(loose).detect_feature(imgs[0])
+        assert np.array_equal(f.get(0)[0], od)
+        f.free()
+    finally:
+        c.close()
