@@ -81,120 +81,161 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 }
 
 // Sample tables: the std::mt19937 draw sequence of TransformEstimation::get_transform with its
-// rejection of repeated indices (transform_estimate.cc:64-77), one wavefront per pair.  The
-// generator state lives in LDS; the 64 lanes regenerate it (the three dependency phases of the
-// twist) and temper + reduce a whole block of 624 draws at once, lane 0 then consumes them in
-// order -- the stream position depends on the rejections, so consumption is sequential.
-__global__ void __launch_bounds__(64) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ seeds,
+// rejection of repeated indices (transform_estimate.cc:64-77), one workgroup per pair.
+//
+// The reference consumes the stream sequentially: hypothesis K takes draws until it holds ns distinct
+// indices, so where a hypothesis starts depends on every rejection before it.  Instead of walking the
+// stream draw by draw (round 1: 1.75 ms, the longest kernel of the whole pipeline), the walk is
+// turned into pointer jumping over a chunk of the stream held in LDS:
+//   1. the generator state is twisted block by block (three dependency phases, all 256 threads) and
+//      every block of 624 draws is tempered and reduced mod m into rd[];
+//   2. next(i) = the stream position right after the sample that STARTS at position i (the first
+//      position by which ns distinct values were seen) is computed for every i independently;
+//   3. the start S[k] of the k-th hypothesis is next^k(0): S[k + 2^r] = next^(2^r)(S[k]) while the
+//      table is squared in place (next^(2^r) -> next^(2^(r+1))), log2(#hypotheses) rounds;
+//   4. every hypothesis is then re-walked from its start in parallel and written out.
+// A chunk that does not hold all hypotheses (tiny m: many rejections) carries the draws of its first
+// incomplete sample to the front of the buffer and goes round again.  The result is, draw for draw,
+// the table the sequential automaton produces (tests: op_ransac_pairs == oracle for injected seeds).
+constexpr int RS_T = 256;
+constexpr int RS_BLK = 22;                 // generator blocks per chunk
+constexpr int RS_N = RS_BLK * 624;         // 13728 draws: 1500 hypotheses of 8 need ~12.4 k at m ~ 100
+constexpr int RS_SMAX = 2048;              // > RS_N / 7 + 2 hypothesis starts per chunk
+constexpr unsigned short RS_END = 0xFFFF;  // "no complete sample starts here"
+
+// position after the sample starting at i, or RS_END when the chunk ends first
+__device__ __forceinline__ unsigned short rs_next(const unsigned short* rd, int i, int N, int ns) {
+	int v[8];
+	if (i + ns <= N) {                     // common case: the next ns draws are already distinct
+		bool dup = false;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) v[q] = q < ns ? (int)rd[i + q] : -1 - q;
+#pragma unroll
+		for (int a = 0; a < 8; ++a)
+#pragma unroll
+			for (int b = a + 1; b < 8; ++b) dup |= v[a] == v[b];
+		if (!dup) return (unsigned short)(i + ns);
+	}
+#pragma unroll
+	for (int q = 0; q < 8; ++q) v[q] = -1;
+	int cnt = 0, j = i;
+	while (cnt < ns && j < N) {
+		const int r = rd[j++];
+		bool dup = false;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) dup |= v[q] == r;
+		if (!dup) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = q == cnt ? r : v[q];
+			++cnt;
+		}
+	}
+	return cnt == ns ? (unsigned short)j : RS_END;
+}
+
+__global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ seeds,
 		int iters, unsigned short* __restrict__ samples) {
 	__shared__ unsigned mt[624];
-	__shared__ unsigned short rd[624];
-	__shared__ unsigned short ob[624];
+	__shared__ unsigned short rd[RS_N + 8];
+	__shared__ unsigned short Ja[RS_N + 2], Jb[RS_N + 2];
+	__shared__ unsigned short S[RS_SMAX];
+	__shared__ int s_cnt;
 	const PairArgs pa = pairs[blockIdx.x];
-	const int m = pa.m, ns = pa.nsample, lane = threadIdx.x;
+	const int m = pa.m, ns = pa.nsample, tid = threadIdx.x;
 	if (m < 8 || m < ns) return;                       // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
-	if (lane == 0) {                                   // std::mt19937::seed
+	if (tid == 0) {                                    // std::mt19937::seed
 		unsigned v = seeds[blockIdx.x]; mt[0] = v;
 		for (int i = 1; i < 624; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i; mt[i] = v; }
 	}
-	__syncthreads();
 	unsigned short* sp = samples + pa.samp_off;
-	int vsel = -1;                                     // lane q < t: q-th index of the sample being drawn, else -1
-	unsigned long long selmask = 0ULL;                 // m <= 64: bit r set = index r already drawn for this sample
-	int K = 0, t = 0, accepted = 0;
-	while (K < iters) {                                // K, t and the sample are wave-uniform
-		// ---- twist (each phase reads only values the previous phases finished) ----
-		unsigned o0[4], o1[4];
-		for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i < 227) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
-		unsigned lastold = mt[623];
-		__syncthreads();
-		for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i < 227) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
-		__syncthreads();
-		// i in [227, 623): mt[i] = mt[i-227](new) ^ f(old[i], old[i+1]) ; chains of stride 227 are at most 2 long
-		for (int r = 0; r < 4; ++r) { const int i = 227 + lane + 64 * r; if (i < 454) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
-		__syncthreads();
-		for (int r = 0; r < 4; ++r) { const int i = 227 + lane + 64 * r; if (i < 454) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
-		__syncthreads();
-		for (int r = 0; r < 3; ++r) { const int i = 454 + lane + 64 * r; if (i < 623) { o0[r] = mt[i]; o1[r] = mt[i + 1]; } }
-		__syncthreads();
-		for (int r = 0; r < 3; ++r) { const int i = 454 + lane + 64 * r; if (i < 623) { const unsigned y = (o0[r] & 0x80000000u) | (o1[r] & 0x7fffffffu); mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); } }
-		__syncthreads();
-		if (lane == 0) { const unsigned y = (lastold & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
-		__syncthreads();
-		// ---- temper + reduce all 624 draws ----
-		for (int i = lane; i < 624; i += 64) {
-			unsigned y = mt[i];
-			y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-			rd[i] = (unsigned short)(y % (unsigned)m);
-		}
-		__syncthreads();
-		// ---- consume the block in order (:70-77).  The automaton is sequential (the stream position
-		// depends on the rejections), so it runs on the scalar unit: 64 draws at a time sit in one
-		// VGPR across the lanes, the sample state and the counters are wave-uniform (SGPR) values,
-		// accepted draws go to the LDS staging buffer.
-		//   m <= 64: the selected set is a 64-bit mask, membership is a scalar bit test;
-		//   m  > 64: repeats are rare, so whole samples are accepted at once when the pairwise
-		//            equality masks of the batch show no repeat among their ns draws, else the
-		//            draws are stepped one by one against the set held across the lanes. ----
-		int cnt = 0;
-		for (int base = 0; base < 624 && K < iters; base += 64) {
-			const int v = base + lane < 624 ? (int)rd[base + lane] : 0;
-			const int lim = 624 - base < 64 ? 624 - base : 64;
-			if (m <= 64) {
-				// branch-free scalar chain: membership, insertion and sample completion are bit
-				// operations on wave-uniform values; the lanes learn afterwards which of the 64 draws
-				// were accepted (bit i of acc) and compact them into the staging buffer in one step.
-				// Draws past the last hypothesis are dropped at the flush below.
-				unsigned long long acc = 0ULL;
-#pragma unroll 16
-				for (int i = 0; i < 64; ++i) {
-					const int r = __builtin_amdgcn_readlane(v, i);
-					const unsigned long long isnew = (i < lim) ? (~(selmask >> r) & 1ULL) : 0ULL;     // already selected? (:73-75)
-					selmask |= isnew << r;
-					acc |= isnew << i;
-					t += (int)isnew;
-					const bool done = t == ns;
-					selmask = done ? 0ULL : selmask;
-					t = done ? 0 : t;
-					K += done ? 1 : 0;
-				}
-				if ((acc >> lane) & 1ULL) ob[cnt + __popcll(acc & ((1ULL << lane) - 1ULL))] = (unsigned short)v;
-				cnt += __popcll(acc);
-			} else {
-				unsigned long long eq[7];                                // bit l of eq[d-1]: draw l == draw l+d
-#pragma unroll
-				for (int d = 1; d <= 7; ++d) {
-					const int o = __shfl_down(v, d);                     // all lanes active: a pull from a masked-off lane reads 0
-					eq[d - 1] = __ballot(lane + d < lim && v == o);
-				}
-				int i = 0;
-				while (i < lim && K < iters) {
-					if (t == 0 && i + ns <= lim) {
-						unsigned long long bad = 0ULL;
-#pragma unroll
-						for (int d = 1; d <= 7; ++d) if (d < ns) bad |= (eq[d - 1] >> i) & ((1ULL << (ns - d)) - 1ULL);
-						if (bad == 0ULL) {                               // ns distinct draws: one whole sample
-							if (lane >= i && lane < i + ns) ob[cnt + lane - i] = (unsigned short)v;
-							cnt += ns; ++K; i += ns;
-							continue;
-						}
-					}
-					const int r = __builtin_amdgcn_readlane(v, i);
-					++i;
-					if (__ballot(vsel == r) != 0ULL) continue;           // already selected; lane q < t holds sel[q]
-					vsel = lane == t ? r : vsel;
-					if (lane == i - 1) ob[cnt] = (unsigned short)v;
-					++cnt;
-					if (++t == ns) { t = 0; ++K; vsel = -1; }
-				}
+	auto twist_word = [](unsigned hi, unsigned lo, unsigned far) {
+		const unsigned y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+		return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+	};
+	int kdone = 0, carry = 0;                          // wave/workgroup-uniform
+	while (kdone < iters) {
+		const int nb = (RS_N - carry) / 624;
+		if (nb < 1) break;                             // one sample longer than 13 k draws: cannot happen for m >= ns
+		for (int b = 0; b < nb; ++b) {
+			// ---- twist: thread t owns words t, 227 + t, 454 + t; the old values every phase needs are
+			// read before anything is overwritten, each phase then reads only finished words ----
+			__syncthreads();
+			unsigned o[6] = {0, 0, 0, 0, 0, 0};
+			if (tid < 227) { o[0] = mt[tid]; o[1] = mt[tid + 1]; o[2] = mt[227 + tid]; o[3] = mt[228 + tid]; }
+			if (tid < 169) { o[4] = mt[454 + tid]; o[5] = mt[455 + tid]; }
+			const unsigned lastold = mt[623];
+			__syncthreads();
+			if (tid < 227) mt[tid] = twist_word(o[0], o[1], mt[tid + 397]);
+			__syncthreads();
+			if (tid < 227) mt[227 + tid] = twist_word(o[2], o[3], mt[tid]);
+			__syncthreads();
+			if (tid < 169) mt[454 + tid] = twist_word(o[4], o[5], mt[227 + tid]);
+			if (tid == 255) mt[623] = twist_word(lastold, mt[0], mt[396]);
+			__syncthreads();
+			// ---- temper + reduce the 624 draws of this block ----
+			for (int i = tid; i < 624; i += RS_T) {
+				unsigned y = mt[i];
+				y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+				rd[carry + b * 624 + i] = (unsigned short)(y % (unsigned)m);
 			}
 		}
+		const int N = carry + nb * 624;
 		__syncthreads();
-		for (int i = lane; i < cnt; i += 64) {           // accepted draw number -> (hypothesis, slot)
-			const int a = accepted + i;
-			if (a / ns < iters) sp[(a / ns) * 8 + a % ns] = ob[i];
+		// ---- next(i) for every start position; next(N) = END ----
+		for (int i = tid; i <= N; i += RS_T) Ja[i] = i < N ? rs_next(rd, i, N, ns) : RS_END;
+		if (tid == 0) { S[0] = 0; s_cnt = 0; }
+		int maxS = N / ns + 2; maxS = maxS < RS_SMAX ? maxS : RS_SMAX;
+		unsigned short* J = Ja; unsigned short* Jn = Jb;
+		for (int known = 1; known < maxS; known <<= 1) {
+			__syncthreads();
+			for (int k = tid; k < known && k + known < maxS; k += RS_T) { const unsigned short sk = S[k]; S[k + known] = sk == RS_END ? RS_END : J[sk]; }
+			if ((known << 1) < maxS)
+				for (int i = tid; i <= N; i += RS_T) { const unsigned short x = J[i]; Jn[i] = x == RS_END ? RS_END : J[x]; }
+			unsigned short* tsw = J; J = Jn; Jn = tsw;
 		}
-		accepted += cnt;
+		__syncthreads();
+		// ---- complete samples of this chunk: k with a valid S[k + 1] (S is increasing, then END) ----
+		{
+			int c = 0;
+			for (int k = tid; k + 1 < maxS; k += RS_T) c += S[k + 1] != RS_END ? 1 : 0;
+			if (c) atomicAdd(&s_cnt, c);
+		}
+		__syncthreads();
+		const int ncomp = s_cnt;
+		const int nemit = ncomp < iters - kdone ? ncomp : iters - kdone;
+		for (int k = tid; k < nemit; k += RS_T) {      // re-walk hypothesis k from its start: its ns distinct draws in order
+			int v[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = -1;
+			int cnt = 0, j = S[k];
+			while (cnt < ns) {
+				const int r = rd[j++];
+				bool dup = false;
+#pragma unroll
+				for (int q = 0; q < 8; ++q) dup |= v[q] == r;
+				if (!dup) {
+#pragma unroll
+					for (int q = 0; q < 8; ++q) v[q] = q == cnt ? r : v[q];
+					++cnt;
+				}
+			}
+			unsigned short* o = sp + (long long)(kdone + k) * 8;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) if (q < ns) o[q] = (unsigned short)v[q];
+		}
+		kdone += ncomp;
+		if (kdone >= iters) break;
+		// ---- carry the draws of the first incomplete sample to the front ----
+		const int p0 = S[ncomp];                       // valid: next of the last complete sample (0 if none)
+		const int L = N - p0;
+		if (ncomp == 0 && L == N && nb * 624 + carry >= RS_N - 623) break;     // no progress possible
+		for (int base = 0; base < L; base += RS_T) {
+			__syncthreads();
+			const unsigned short val = base + tid < L ? rd[p0 + base + tid] : (unsigned short)0;
+			__syncthreads();
+			if (base + tid < L) rd[base + tid] = val;
+		}
+		carry = L;
 	}
 }
 
@@ -420,7 +461,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
 	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
 	{ ProfScope ps2(ctx, "ransac mt19937 samples");
-	  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(64), 0, st, d_pa, d_seeds, iters, d_samp);
+	  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(RS_T), 0, st, d_pa, d_seeds, iters, d_samp);
 	  RCHK(hipGetLastError()); }
 	// pass 2, overlapped with the (latency-bound) sampling kernel: gather the matched point pairs
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac gather points (host)"));

@@ -104,3 +104,28 @@ def test_ransac_rejects_foreign_match_indices(ctx, cfg):
     with pytest.raises(hip.OpenPanoHipError):                                      # op_matches of 2 pairs, pair list of 1
         hip.ransac_pairs(ctx, cfg, f, two, [(0, 1)], [(100, 100)] * 2, seeds=[1])
     bad.free(); two.free(); f.free()
+
+
+def test_small_match_lists_span_several_stream_chunks(ctx, oracle, cfg):
+    """With few matches almost every draw repeats an index already in the sample (m = 8: ~22 draws per
+    8-point sample), so 1500 hypotheses need far more than one LDS chunk of the mt19937 stream: the
+    sample kernel carries its incomplete sample across chunks.  Same winner / inliers as the oracle."""
+    from openpano_amd import hip
+    from openpano_amd.config import PanoConfig
+    views = synth.image_set(2, 400, 600, seed=5, overlap=0.5)
+    f = hip.sift_batch(ctx, cfg, views)
+    coors = [f.get(i)[1] for i in range(2)]
+    full = hip.match_pairs(ctx, cfg, f, [(0, 1)])[0]
+    assert len(full) > 70
+    sizes = [8, 9, 10, 12, 16, 20, 33, 64, 65, len(full)]
+    lists = [full[:: max(1, len(full) // k)][:k] for k in sizes]
+    assert [len(x) for x in lists] == sizes
+    mh = hip.Matches.from_host(lists)
+    pairs = [(0, 1)] * len(sizes)
+    seeds = [900 + k for k in range(len(sizes))]
+    cyl = PanoConfig(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1)
+    for c in (cfg, cyl):                                 # 8-point homography and 7-point affine samples
+        res = hip.ransac_pairs(ctx, c, f, mh, pairs, [(600, 400)] * 2, seeds=seeds)
+        for k in range(len(sizes)):
+            _check(oracle, res[k], lists[k], coors[0], coors[1], (600, 400), (600, 400), seeds[k], cfg=c if c is cyl else None)
+    mh.free(); f.free()
