@@ -50,9 +50,10 @@ constexpr int RANSAC_PTS_CHUNK = 512;
 
 // grid (ceil(iters/256), npairs)
 __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__ pairs, const double* __restrict__ pts /* m x {p1x,p1y,p2x,p2y} */,
-		const unsigned short* __restrict__ samples, int iters, int* __restrict__ counts /* npairs x iters */) {
+		const unsigned short* __restrict__ samples, int iters, int* __restrict__ counts /* npairs x iters */, const int* __restrict__ active) {
 	__shared__ double s_pts[RANSAC_PTS_CHUNK * 4];
-	const PairArgs pa = pairs[blockIdx.y];
+	const int pair = active[blockIdx.y];
+	const PairArgs pa = pairs[pair];
 	const int hyp = blockIdx.x * 256 + threadIdx.x;
 	const double* P = pts + (long long)pa.pts_off * 4;
 	double H[9];
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 			for (int i = 0; i < cn; ++i)
 				cnt += opransac::is_inlier(H, P2{s_pts[4 * i], s_pts[4 * i + 1]}, P2{s_pts[4 * i + 2], s_pts[4 * i + 3]}, pa.inlier_dist) ? 1 : 0;
 	}
-	if (hyp < iters) counts[(long long)blockIdx.y * iters + hyp] = ok ? cnt : -1;
+	if (hyp < iters) counts[(long long)pair * iters + hyp] = ok ? cnt : -1;
 }
 
 // Sample tables: the std::mt19937 draw sequence of TransformEstimation::get_transform with its
@@ -97,73 +98,169 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 // A chunk that does not hold all hypotheses (tiny m: many rejections) carries the draws of its first
 // incomplete sample to the front of the buffer and goes round again.  The result is, draw for draw,
 // the table the sequential automaton produces (tests: op_ransac_pairs == oracle for injected seeds).
-constexpr int RS_T = 256;
-constexpr int RS_BLK = 22;                 // generator blocks per chunk
-constexpr int RS_N = RS_BLK * 624;         // 13728 draws: 1500 hypotheses of 8 need ~12.4 k at m ~ 100
-constexpr int RS_SMAX = 2048;              // > RS_N / 7 + 2 hypothesis starts per chunk
+constexpr int RS_T = 512;                  // 8 wavefronts per workgroup, 4 workgroups per CU (LDS): every live pair of a config-4 job is resident at once
+constexpr int RS_BLK = 9;                  // generator blocks per chunk (38 KB of LDS: four workgroups per CU)
+constexpr int RS_N = RS_BLK * 624;         // 5616 draws; 1500 hypotheses of 8 need ~12.4 k at m ~ 100: a few chunks, each sized to what is left
+constexpr int RS_SMAX = 1024;              // > RS_N / 7 + 2 hypothesis starts per chunk
+constexpr int RS_W = 16;                   // draws of a sample walk that are pre-loaded into registers
+constexpr int RS_LB = 24;                  // look-back of the previous-equal-draw table; longer samples take the exact walk
 constexpr unsigned short RS_END = 0xFFFF;  // "no complete sample starts here"
 
-// position after the sample starting at i, or RS_END when the chunk ends first
-__device__ __forceinline__ unsigned short rs_next(const unsigned short* rd, int i, int N, int ns) {
-	int v[8];
-	if (i + ns <= N) {                     // common case: the next ns draws are already distinct
-		bool dup = false;
+// Walk the sample that starts at stream position i: ns distinct values in draw order (v[]), returns
+// the position right after its last draw, or -1 when the chunk [0, N) ends first.  The first RS_W
+// draws are loaded up front (independent LDS reads) and consumed from registers; only a sample with
+// more than RS_W - ns rejections continues with dependent reads.
+__device__ __forceinline__ int rs_walk(const unsigned short* rd, int i, int N, int ns, int (&v)[8]) {
+	int w[RS_W];
 #pragma unroll
-		for (int q = 0; q < 8; ++q) v[q] = q < ns ? (int)rd[i + q] : -1 - q;
-#pragma unroll
-		for (int a = 0; a < 8; ++a)
-#pragma unroll
-			for (int b = a + 1; b < 8; ++b) dup |= v[a] == v[b];
-		if (!dup) return (unsigned short)(i + ns);
-	}
+	for (int j = 0; j < RS_W; ++j) w[j] = i + j < N ? (int)rd[i + j] : -2 - j;
 #pragma unroll
 	for (int q = 0; q < 8; ++q) v[q] = -1;
-	int cnt = 0, j = i;
-	while (cnt < ns && j < N) {
-		const int r = rd[j++];
-		bool dup = false;
+	int cnt = 0, end = -1;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) dup |= v[q] == r;
-		if (!dup) {
+	for (int j = 0; j < RS_W; ++j) {
+		const int r = w[j];
+		bool take = cnt < ns && r >= 0;
 #pragma unroll
-			for (int q = 0; q < 8; ++q) v[q] = q == cnt ? r : v[q];
-			++cnt;
-		}
+		for (int q = 0; q < 8; ++q) take = take && v[q] != r;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) v[q] = (take && q == cnt) ? r : v[q];
+		cnt += take ? 1 : 0;
+		end = (take && cnt == ns) ? i + j + 1 : end;
 	}
-	return cnt == ns ? (unsigned short)j : RS_END;
+	if (cnt < ns) {
+		int j = i + RS_W;
+		while (cnt < ns && j < N) {
+			const int r = rd[j++];
+			bool take = true;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) take = take && v[q] != r;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = (take && q == cnt) ? r : v[q];
+			cnt += take ? 1 : 0;
+		}
+		end = cnt == ns ? j : -1;
+	}
+	return end;
 }
 
-__global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ seeds,
-		int iters, unsigned short* __restrict__ samples) {
+// m <= 64: the selected set of a sample is a 64-bit mask (transform_estimate.cc:73-75 as a bit test),
+// exact for any sample length.  Returns the end position (or -1 when the chunk ends first); with
+// OUT the accepted draws are also returned in order.
+template <bool OUT>
+__device__ __forceinline__ int rs_walk_mask(const unsigned short* rd, int i, int N, int ns, int (&v)[8]) {
+	int w[RS_W];
+#pragma unroll
+	for (int j = 0; j < RS_W; ++j) w[j] = i + j < N ? (int)rd[i + j] : -1;
+	unsigned long long mask = 0ULL;
+	int cnt = 0, end = -1;
+#pragma unroll
+	for (int j = 0; j < RS_W; ++j) {
+		const int r = w[j];
+		const unsigned long long bit = 1ULL << (r & 63);
+		const bool take = cnt < ns && r >= 0 && !(mask & bit);
+		if (OUT) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = (take && q == cnt) ? r : v[q];
+		}
+		mask |= take ? bit : 0ULL;
+		cnt += take ? 1 : 0;
+		end = (take && cnt == ns) ? i + j + 1 : end;
+	}
+	if (cnt < ns) {
+		int j = i + RS_W;
+		while (cnt < ns && j < N) {
+			const int r = rd[j++];
+			const unsigned long long bit = 1ULL << r;
+			const bool take = !(mask & bit);
+			if (OUT) {
+#pragma unroll
+				for (int q = 0; q < 8; ++q) v[q] = (take && q == cnt) ? r : v[q];
+			}
+			mask |= bit;
+			cnt += take ? 1 : 0;
+		}
+		end = cnt == ns ? j : -1;
+	}
+	return end;
+}
+
+// next(i) through the previous-equal-draw table: PP[t] = 1 + position of the nearest earlier draw
+// with the same value within RS_LB positions, 0 if none.  Inside the sample that starts at i, draw t
+// is a repeat exactly if an equal draw lies in [i, t) -- i.e. PP[t] > i (if the nearest equal draw
+// inside the sample was itself rejected, an earlier equal one was accepted) -- so the walk is one
+// compare per draw.  Valid while the sample spans at most RS_LB positions; longer ones (many
+// rejections: tiny m) return -2 and take the exact value-comparing walk.
+__device__ __forceinline__ int rs_next_fast(const unsigned short* PP, int i, int N, int ns) {
+	int cnt = 0, end = -1;
+	unsigned short w[RS_W];
+#pragma unroll
+	for (int j = 0; j < RS_W; ++j) w[j] = PP[i + j];                  // PP is padded past N
+#pragma unroll
+	for (int j = 0; j < RS_W; ++j) {
+		const bool take = cnt < ns && i + j < N && (int)w[j] <= i;
+		cnt += take ? 1 : 0;
+		end = (take && cnt == ns) ? i + j + 1 : end;
+	}
+	if (cnt < ns) {
+		int j = i + RS_W;
+		const int lim = i + RS_LB < N ? i + RS_LB : N;
+		while (cnt < ns && j < lim) { cnt += (int)PP[j] <= i ? 1 : 0; ++j; }
+		if (cnt == ns) end = j;
+		else end = j >= N ? -1 : -2;               // chunk exhausted : sample longer than the look-back
+	}
+	return end;
+}
+
+// std::mt19937::seed for every pair at once (thread per pair; the recurrence is serial in i)
+__global__ void __launch_bounds__(64) k_ransac_seed(const unsigned* __restrict__ seeds, const int* __restrict__ active, int nactive, unsigned* __restrict__ state /* 624 x nactive */) {
+	const int q = blockIdx.x * 64 + threadIdx.x;
+	if (q >= nactive) return;
+	const int p = active[q];
+	unsigned v = seeds[p];
+	unsigned* st = state + q;                          // word-major: the lanes of a wavefront store to one cache line
+	st[0] = v;
+	for (int i = 1; i < 624; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i; st[(long long)i * nactive] = v; }
+}
+
+__global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ state,
+		int iters, unsigned short* __restrict__ samples, const int* __restrict__ active) {
 	__shared__ unsigned mt[624];
 	__shared__ unsigned short rd[RS_N + 8];
-	__shared__ unsigned short Ja[RS_N + 2], Jb[RS_N + 2];
+	__shared__ unsigned short Ja[RS_N + 2], Jb[RS_N + RS_W + 2];         // Jb doubles as the previous-equal table before the squaring starts
 	__shared__ unsigned short S[RS_SMAX];
 	__shared__ int s_cnt;
-	const PairArgs pa = pairs[blockIdx.x];
+	const int pair = active[blockIdx.x];               // only pairs with enough matches get a workgroup (the host compacts the list)
+	const PairArgs pa = pairs[pair];
 	const int m = pa.m, ns = pa.nsample, tid = threadIdx.x;
 	if (m < 8 || m < ns) return;                       // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
-	if (tid == 0) {                                    // std::mt19937::seed
-		unsigned v = seeds[blockIdx.x]; mt[0] = v;
-		for (int i = 1; i < 624; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i; mt[i] = v; }
-	}
+	for (int i = tid; i < 624; i += RS_T) mt[i] = state[(long long)i * gridDim.x + blockIdx.x];
 	unsigned short* sp = samples + pa.samp_off;
 	auto twist_word = [](unsigned hi, unsigned lo, unsigned far) {
 		const unsigned y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
 		return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 	};
-	int kdone = 0, carry = 0;                          // wave/workgroup-uniform
+	int kdone = 0, carry = 0;                          // workgroup-uniform
+	// expected draws per sample, x16: sum over the ns picks of m / (m - picks so far); re-measured after every chunk
+	long long draws_per_sample_x16 = 0;
+	for (int q = 0; q < ns; ++q) draws_per_sample_x16 += (16LL * m + (m - q) - 1) / (m - q);
 	while (kdone < iters) {
-		const int nb = (RS_N - carry) / 624;
-		if (nb < 1) break;                             // one sample longer than 13 k draws: cannot happen for m >= ns
+		int nb = (RS_N - carry) / 624;
+		if (nb < 1) break;                             // one sample longer than 11 k draws: cannot happen for m >= ns
+		{                                              // only what the remaining hypotheses are expected to draw (+12 %)
+			const long long need = (long long)(iters - kdone) * draws_per_sample_x16 / 16;
+			const long long want = (need + need / 8 + 32 - carry + 623) / 624;
+			nb = want < 1 ? 1 : (want < nb ? (int)want : nb);
+		}
 		for (int b = 0; b < nb; ++b) {
 			// ---- twist: thread t owns words t, 227 + t, 454 + t; the old values every phase needs are
 			// read before anything is overwritten, each phase then reads only finished words ----
 			__syncthreads();
 			unsigned o[6] = {0, 0, 0, 0, 0, 0};
+			unsigned lastold = 0;
 			if (tid < 227) { o[0] = mt[tid]; o[1] = mt[tid + 1]; o[2] = mt[227 + tid]; o[3] = mt[228 + tid]; }
 			if (tid < 169) { o[4] = mt[454 + tid]; o[5] = mt[455 + tid]; }
-			const unsigned lastold = mt[623];
+			if (tid == 255) lastold = mt[623];
 			__syncthreads();
 			if (tid < 227) mt[tid] = twist_word(o[0], o[1], mt[tid + 397]);
 			__syncthreads();
@@ -182,15 +279,41 @@ __global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restr
 		const int N = carry + nb * 624;
 		__syncthreads();
 		// ---- next(i) for every start position; next(N) = END ----
-		for (int i = tid; i <= N; i += RS_T) Ja[i] = i < N ? rs_next(rd, i, N, ns) : RS_END;
+		if (m <= 64) {
+			for (int i = tid; i <= N; i += RS_T) {
+				int v[8];
+				const int e = i < N ? rs_walk_mask<false>(rd, i, N, ns, v) : -1;
+				Ja[i] = e < 0 ? RS_END : (unsigned short)e;
+			}
+		} else {
+			// previous-equal-draw table (into Jb) first
+			for (int t = tid; t < N + RS_W; t += RS_T) {
+				int dd = 0;
+				if (t < N) {
+					const int x = rd[t];
+					const int lb = t < RS_LB ? t : RS_LB;
+#pragma unroll
+					for (int d = RS_LB; d >= 1; --d) dd = (d <= lb && (int)rd[t - (d <= lb ? d : 0)] == x) ? d : dd;     // the nearest match wins
+				}
+				Jb[t] = dd ? (unsigned short)(t - dd + 1) : (unsigned short)0;
+			}
+			__syncthreads();
+			for (int i = tid; i <= N; i += RS_T) {
+				int e = i < N ? rs_next_fast(Jb, i, N, ns) : -1;
+				if (e == -2) { int v[8]; e = rs_walk(rd, i, N, ns, v); }
+				Ja[i] = e < 0 ? RS_END : (unsigned short)e;
+			}
+		}
 		if (tid == 0) { S[0] = 0; s_cnt = 0; }
 		int maxS = N / ns + 2; maxS = maxS < RS_SMAX ? maxS : RS_SMAX;
 		unsigned short* J = Ja; unsigned short* Jn = Jb;
 		for (int known = 1; known < maxS; known <<= 1) {
 			__syncthreads();
 			for (int k = tid; k < known && k + known < maxS; k += RS_T) { const unsigned short sk = S[k]; S[k + known] = sk == RS_END ? RS_END : J[sk]; }
-			if ((known << 1) < maxS)
+			if ((known << 1) < maxS) {
+#pragma unroll 4
 				for (int i = tid; i <= N; i += RS_T) { const unsigned short x = J[i]; Jn[i] = x == RS_END ? RS_END : J[x]; }
+			}
 			unsigned short* tsw = J; J = Jn; Jn = tsw;
 		}
 		__syncthreads();
@@ -205,30 +328,22 @@ __global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restr
 		const int nemit = ncomp < iters - kdone ? ncomp : iters - kdone;
 		for (int k = tid; k < nemit; k += RS_T) {      // re-walk hypothesis k from its start: its ns distinct draws in order
 			int v[8];
+			if (m <= 64) {
 #pragma unroll
-			for (int q = 0; q < 8; ++q) v[q] = -1;
-			int cnt = 0, j = S[k];
-			while (cnt < ns) {
-				const int r = rd[j++];
-				bool dup = false;
-#pragma unroll
-				for (int q = 0; q < 8; ++q) dup |= v[q] == r;
-				if (!dup) {
-#pragma unroll
-					for (int q = 0; q < 8; ++q) v[q] = q == cnt ? r : v[q];
-					++cnt;
-				}
-			}
+				for (int q = 0; q < 8; ++q) v[q] = -1;
+				rs_walk_mask<true>(rd, S[k], N, ns, v);
+			} else rs_walk(rd, S[k], N, ns, v);
 			unsigned short* o = sp + (long long)(kdone + k) * 8;
 #pragma unroll
 			for (int q = 0; q < 8; ++q) if (q < ns) o[q] = (unsigned short)v[q];
 		}
 		kdone += ncomp;
 		if (kdone >= iters) break;
+		if (ncomp > 0) draws_per_sample_x16 = 16LL * S[ncomp] / ncomp + 1;
 		// ---- carry the draws of the first incomplete sample to the front ----
 		const int p0 = S[ncomp];                       // valid: next of the last complete sample (0 if none)
 		const int L = N - p0;
-		if (ncomp == 0 && L == N && nb * 624 + carry >= RS_N - 623) break;     // no progress possible
+		if (ncomp == 0 && L >= RS_N - 623) break;      // no progress possible (a sample longer than the whole buffer)
 		for (int base = 0; base < L; base += RS_T) {
 			__syncthreads();
 			const unsigned short val = base + tid < L ? rd[p0 + base + tid] : (unsigned short)0;
@@ -241,9 +356,10 @@ __global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restr
 
 // first hypothesis with the maximal inlier count (update_max, transform_estimate.cc:82)
 __global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ counts, int iters, int2* __restrict__ best,
-		const PairArgs* __restrict__ pairs, const unsigned short* __restrict__ samples, unsigned short* __restrict__ best_samp) {
+		const PairArgs* __restrict__ pairs, const unsigned short* __restrict__ samples, unsigned short* __restrict__ best_samp, const int* __restrict__ active) {
 	__shared__ int s_cnt[256], s_idx[256];
-	const int* c = counts + (long long)blockIdx.x * iters;
+	const int pair = active[blockIdx.x];
+	const int* c = counts + (long long)pair * iters;
 	int bc = -1, bi = -1;
 	for (int i = threadIdx.x; i < iters; i += 256) { const int v = c[i]; if (v > bc) { bc = v; bi = i; } }
 	s_cnt[threadIdx.x] = bc; s_idx[threadIdx.x] = bi;
@@ -255,10 +371,10 @@ __global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ cou
 		}
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) best[blockIdx.x] = make_int2(s_idx[0], s_cnt[0]);
+	if (threadIdx.x == 0) best[pair] = make_int2(s_idx[0], s_cnt[0]);
 	if (threadIdx.x < 8) {     // the winner's sample, for the host epilogue
 		const int bi0 = s_idx[0];
-		best_samp[blockIdx.x * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[blockIdx.x].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
+		best_samp[pair * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[pair].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
 	}
 }
 
@@ -439,6 +555,9 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		pa[p] = PairArgs{(int)pts_total, h.m, affine ? 1 : 0, nsample, (double)inlier_dist, (long long)p * iters * 8};
 		pts_total += h.m;
 	}
+	std::vector<int> h_active;
+	for (int p = 0; p < npairs; ++p) if (ph[p].m >= 8 && ph[p].m >= nsample) h_active.push_back(p);
+	const int nactive = (int)h_active.size();
 	// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
 	std::vector<unsigned> h_seeds(npairs);
 	for (int p = 0; p < npairs; ++p) h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
@@ -446,7 +565,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
 	PairArgs* d_pa = nullptr; double* d_pts = nullptr; unsigned short* d_samp = nullptr; int* d_counts = nullptr; int2* d_best = nullptr;
-	unsigned* d_seeds = nullptr; unsigned short* d_bsamp = nullptr;
+	unsigned* d_seeds = nullptr; unsigned* d_state = nullptr; unsigned short* d_bsamp = nullptr; int* d_active = nullptr;
 	std::vector<int2> best(npairs);
 	std::vector<unsigned short> best_samp((size_t)npairs * 8);
 	int rc = OP_OK;
@@ -455,13 +574,24 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	RCHK(pool_alloc((void**)&d_pts, sizeof(double) * pts_flat.size()));
 	RCHK(pool_alloc((void**)&d_samp, sizeof(unsigned short) * (size_t)npairs * iters * 8));
 	RCHK(pool_alloc((void**)&d_seeds, sizeof(unsigned) * npairs));
+	RCHK(pool_alloc((void**)&d_active, sizeof(int) * npairs));
+	RCHK(pool_alloc((void**)&d_state, sizeof(unsigned) * 624 * (size_t)npairs));
 	RCHK(pool_alloc((void**)&d_bsamp, sizeof(unsigned short) * 8 * npairs));
 	RCHK(pool_alloc((void**)&d_counts, sizeof(int) * (size_t)npairs * iters));
 	RCHK(pool_alloc((void**)&d_best, sizeof(int2) * npairs));
 	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
 	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
 	{ ProfScope ps2(ctx, "ransac mt19937 samples");
-	  hipLaunchKernelGGL(k_ransac_samples, dim3(npairs), dim3(RS_T), 0, st, d_pa, d_seeds, iters, d_samp);
+	  // pairs below the match-count gate (:21,39,55) never get a workgroup: launching 1024-thread groups that
+	  // exit at once costs more dispatcher time than the live ones compute (703 pairs, ~1/6 live on config 4)
+	  RCHK(hipMemsetAsync(d_best, 0xFF, sizeof(int2) * npairs, st));
+	  RCHK(hipMemsetAsync(d_bsamp, 0, sizeof(unsigned short) * 8 * npairs, st));
+	  if (nactive) {
+	    RCHK(hipMemcpyAsync(d_active, h_active.data(), sizeof(int) * nactive, hipMemcpyHostToDevice, st));
+	    hipLaunchKernelGGL(k_ransac_seed, dim3((nactive + 63) / 64), dim3(64), 0, st, d_seeds, d_active, nactive, d_state);
+	    RCHK(hipGetLastError());
+	    hipLaunchKernelGGL(k_ransac_samples, dim3(nactive), dim3(RS_T), 0, st, d_pa, d_state, iters, d_samp, d_active);
+	  }
 	  RCHK(hipGetLastError()); }
 	// pass 2, overlapped with the (latency-bound) sampling kernel: gather the matched point pairs
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac gather points (host)"));
@@ -479,9 +609,11 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	RCHK(hipMemcpyAsync(d_pts, pts_flat.data(), sizeof(double) * pts_flat.size(), hipMemcpyHostToDevice, st));
 	{
 		ProfScope ps(ctx, "ransac hypotheses");
-		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, npairs), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts);
+		if (nactive) {
+		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, nactive), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts, d_active);
 		RCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_ransac_best, dim3(npairs), dim3(256), 0, st, d_counts, iters, d_best, d_pa, d_samp, d_bsamp);
+		hipLaunchKernelGGL(k_ransac_best, dim3(nactive), dim3(256), 0, st, d_counts, iters, d_best, d_pa, d_samp, d_bsamp, d_active);
+		}
 		RCHK(hipGetLastError());
 	}
 	RCHK(hipMemcpyAsync(best.data(), d_best, sizeof(int2) * npairs, hipMemcpyDeviceToHost, st));
@@ -549,7 +681,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	});
 done:
 	hs.reset();
-	pool_free(d_pa); pool_free(d_pts); pool_free(d_samp); pool_free(d_counts); pool_free(d_best); pool_free(d_seeds); pool_free(d_bsamp);
+	pool_free(d_pa); pool_free(d_pts); pool_free(d_samp); pool_free(d_counts); pool_free(d_best); pool_free(d_seeds); pool_free(d_state); pool_free(d_active); pool_free(d_bsamp);
 #undef RCHK
 	if (rc != OP_OK) { delete R; return rc; }
 	*out = R;
