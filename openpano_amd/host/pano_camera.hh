@@ -15,8 +15,14 @@
 // Used standalone (pano_types.hh); with -DOPENPANO_WITH_REFERENCE the reference's own classes
 // are in scope instead and this header is not included.
 #pragma once
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <array>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <limits>
 #include <queue>
@@ -162,6 +168,25 @@ class Camera {
 		}
 };
 
+// wall-clock split of the bundle adjuster (printed by CameraEstimator::estimate when PANO_BA_PROFILE is set)
+struct BaProfile { double t_err = 0, t_jac = 0, t_solve = 0; long n_iter = 0, n_opt = 0; };
+inline BaProfile& ba_prof() { static BaProfile p; return p; }
+// OpenMP team of the bundle adjuster: a few hundred parallel regions of well under a millisecond
+// each, so a team spanning every logical CPU of a big host spends more in fork/join than it gains
+inline int ba_threads() {
+	static const int n = [] {
+		int t = 1;
+#ifdef _OPENMP
+		t = omp_get_max_threads();
+		if (t > 32) t = 32;
+#endif
+		if (const char* e = std::getenv("PANO_BA_THREADS")) { const int v = std::atoi(e); if (v > 0) t = v; }
+		return t;
+	}();
+	return n;
+}
+inline double ba_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 class IncrementalBundleAdjuster {
 	public:
 		struct ErrorStats {
@@ -200,6 +225,7 @@ class IncrementalBundleAdjuster {
 		// Levenberg-Marquardt with the acceptance rule of :125-177
 		void optimize() {
 			if (idx_added.empty()) pano_error_exit("Calling optimize() without adding any matches!");
+			ba_prof().n_opt++;
 			update_index_map();
 			const int nr_img = (int)idx_added.size();
 			JtJ.assign((size_t)(NR_PARAM_PER_CAMERA * nr_img) * (NR_PARAM_PER_CAMERA * nr_img), 0.0);
@@ -306,9 +332,13 @@ class IncrementalBundleAdjuster {
 
 		ErrorStats calcError(const ParamState& state) {            // :179-206
 			ErrorStats ret(nr_pointwise_match * NR_TERM_PER_MATCH);
+			const double t0 = ba_now();
 			auto cameras = state.get_cameras();
-			int idx = 0;
-			for (auto& pair : match_pairs) {
+			const int npairs = (int)match_pairs.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads())            // independent residuals: each pair writes its own slice
+			for (int q = 0; q < npairs; ++q) {
+				const MatchPair& pair = match_pairs[q];
+				int idx = match_cnt_prefix_sum[q] * 2;
 				const int from = index_map[pair.from], to = index_map[pair.to];
 				auto& c_from = cameras[from]; auto& c_to = cameras[to];
 				const Homography Hto_to_from = (c_from.K() * c_from.R) * (c_to.Rinv() * c_to.K().inverse());
@@ -321,25 +351,60 @@ class IncrementalBundleAdjuster {
 				}
 			}
 			ret.update_stats(inlier_threshold);
+			ba_prof().t_err += ba_now() - t0;
 			return ret;
 		}
 
 		// (JtJ + damping) x = J^T r  (:231-251)
 		std::vector<double> get_param_update(const ParamState& state, const std::vector<double>& residual, float lambda) {
 			const int nr_img = (int)idx_added.size(), np = nr_img * NR_PARAM_PER_CAMERA;
+			double t0 = ba_now();
 			calcJacobianSymbolic(state, residual);
+			ba_prof().t_jac += ba_now() - t0; t0 = ba_now();
 			for (int i = 0; i < np; ++i) {
 				if (i % NR_PARAM_PER_CAMERA >= 3) JtJ[(size_t)i * np + i] += lambda;
 				else JtJ[(size_t)i * np + i] += lambda / 10.f;
 			}
 			std::vector<double> x(np, 0.0);
 			pano_la::colpiv_qr_solve(JtJ.data(), np, Jtr.data(), x.data());
+			ba_prof().t_solve += ba_now() - t0; ba_prof().n_iter++;
 			return x;
 		}
 
 		// Analytic derivatives of the residuals (Brown & Lowe, IJCV'07, section 4) -> JtJ and J^T r (:276-385)
+		//
+		// The reference walks the matches once and adds every match's 12 x 12 outer product into JtJ
+		// as it goes.  Here the same additions are made in the same order for every entry, but in two
+		// parallel phases (OpenMP): (1) the derivative rows dx[12], dy[12] of every match, independent
+		// of each other, are computed into a table; (2) every 6 x 6 block of JtJ (one per camera on the
+		// diagonal, one per connected camera pair off it) and every camera's slice of J^T r is owned by
+		// ONE task that walks the match pairs touching it in the reference's order and accumulates its
+		// entries sequentially.  An entry's chain of fp64 additions is therefore the reference's chain,
+		// term for term; only which thread executes it changed.
+		std::vector<double> deriv;          // 24 doubles per pointwise match: dx[0..11], dy[0..11]
+		std::vector<std::vector<int>> cam_pairs;                       // per camera: match-pair indices touching it, ascending
+		std::vector<std::pair<std::pair<int, int>, std::vector<int>>> block_pairs;    // per connected camera pair (i < j): match-pair indices, ascending
+		size_t topo_pairs = (size_t)-1; int topo_imgs = -1;
+
+		void update_topology(int nr_img) {
+			if (topo_pairs == match_pairs.size() && topo_imgs == nr_img) return;
+			cam_pairs.assign(nr_img, {});
+			std::vector<std::vector<int>> blk((size_t)nr_img * nr_img);
+			for (size_t q = 0; q < match_pairs.size(); ++q) {
+				const int f = index_map[match_pairs[q].from], t = index_map[match_pairs[q].to];
+				cam_pairs[f].push_back((int)q);
+				if (t != f) cam_pairs[t].push_back((int)q);
+				blk[(size_t)std::min(f, t) * nr_img + std::max(f, t)].push_back((int)q);
+			}
+			block_pairs.clear();
+			for (int i = 0; i < nr_img; ++i) for (int j = i + 1; j < nr_img; ++j)
+				if (!blk[(size_t)i * nr_img + j].empty()) block_pairs.push_back({{i, j}, std::move(blk[(size_t)i * nr_img + j])});
+			topo_pairs = match_pairs.size(); topo_imgs = nr_img;
+		}
+
 		void calcJacobianSymbolic(const ParamState& state, const std::vector<double>& residual) {
-			const int np = (int)idx_added.size() * NR_PARAM_PER_CAMERA;
+			const int nr_img = (int)idx_added.size();
+			const int np = nr_img * NR_PARAM_PER_CAMERA;
 			std::fill(JtJ.begin(), JtJ.end(), 0.0);
 			std::fill(Jtr.begin(), Jtr.end(), 0.0);
 			const auto& cameras = state.get_cameras();
@@ -347,12 +412,15 @@ class IncrementalBundleAdjuster {
 			for (size_t i = 0; i < cameras.size(); ++i) all_dRdvi[i] = dRdvi(cameras[i].R);
 			const double kf[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0}, kx[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0}, ky[9] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
 			const Homography dKdfocal(kf), dKdppx(kx), dKdppy(ky);
+			update_topology(nr_img);
+			deriv.resize((size_t)nr_pointwise_match * 24);
+			const int npairs = (int)match_pairs.size();
 
-			for (size_t pair_idx = 0; pair_idx < match_pairs.size(); ++pair_idx) {
+			// ---- phase 1: derivative rows of every match
+#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads())
+			for (int pair_idx = 0; pair_idx < npairs; ++pair_idx) {
 				const MatchPair& pair = match_pairs[pair_idx];
-				int idx = match_cnt_prefix_sum[pair_idx] * 2;
 				const int from = index_map[pair.from], to = index_map[pair.to];
-				const int param_idx_from = from * NR_PARAM_PER_CAMERA, param_idx_to = to * NR_PARAM_PER_CAMERA;
 				const auto& c_from = cameras[from]; const auto& c_to = cameras[to];
 				const auto fromK = c_from.K();
 				const auto toKinv = c_to.Kinv();
@@ -370,17 +438,7 @@ class IncrementalBundleAdjuster {
 				const Homography Cto[3] = {Mto * dKdfocal, Mto * dKdppx, Mto * dKdppy};
 				const Homography Mrot = fromK * c_from.R;                            // d/d(R_to): (Mrot dR_i^T) * (Kinv_to p)
 				const Homography Dto[3] = {Mrot * dRtodviT[0], Mrot * dRtodviT[1], Mrot * dRtodviT[2]};
-
-				// This pair only touches the (from, to) rows/columns of JtJ and J^T r: work on a local
-				// 12 x 12 copy and put it back -- every entry still receives the same additions in the
-				// same order, from L1 instead of a 6n x 6n matrix.
-				int gi[12];
-				for (int i = 0; i < 6; ++i) { gi[i] = param_idx_from + i; gi[6 + i] = param_idx_to + i; }
-				// Upper triangle only: the reference adds the same value to JtJ(a, b) and JtJ(b, a)
-				// (:357-381), so the two stay bit-equal and the lower half is a copy at write-back.
-				double L[12][12], g[12];
-				for (int a = 0; a < 12; ++a) { g[a] = Jtr[gi[a]]; for (int b = a; b < 12; ++b) L[a][b] = JtJ[(size_t)gi[a] * np + gi[b]]; }
-
+				double* row = deriv.data() + (size_t)match_cnt_prefix_sum[pair_idx] * 24;
 				for (const auto& p : pair.m.match) {
 					const Vec2D to2 = p.first;
 					const Vec homo = Hto_to_from.trans(to2);
@@ -388,7 +446,7 @@ class IncrementalBundleAdjuster {
 					const double hz_inv = 1.0 / homo.z;
 					// d(residual)/d(variable) = -d(point 2d)/d(homo 3d) * d(homo 3d)/d(variable);
 					// dx / dy: 0..5 = d/d(from params), 6..11 = d/d(to params)
-					double dx[12], dy[12];
+					double* dx = row; double* dy = row + 12;
 					auto drdv = [&](int k, const Vec& dhdv) {
 						dx[k] = -dhdv.x * hz_inv + dhdv.z * homo.x * hz_sqr_inv;
 						dy[k] = -dhdv.y * hz_inv + dhdv.z * homo.y * hz_sqr_inv;
@@ -410,18 +468,66 @@ class IncrementalBundleAdjuster {
 					drdv(9, Dto[0].trans(dot_u2));
 					drdv(10, Dto[1].trans(dot_u2));
 					drdv(11, Dto[2].trans(dot_u2));
-
-					// J^T r, the two rows of this match (J itself is never stored)
-					const double rx = residual[idx], ry = residual[idx + 1];
-					for (int a = 0; a < 12; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
-					// JtJ: every entry gets  += d_a . d_b  (Vec2D::dot: x*x' + y*y')
-					for (int a = 0; a < 12; ++a)
-						for (int b = a; b < 12; ++b) L[a][b] += dx[a] * dx[b] + dy[a] * dy[b];
-					idx += 2;
+					row += 24;
 				}
-				for (int a = 0; a < 12; ++a) {
-					Jtr[gi[a]] = g[a];
-					for (int b = a; b < 12; ++b) { JtJ[(size_t)gi[a] * np + gi[b]] = L[a][b]; JtJ[(size_t)gi[b] * np + gi[a]] = L[a][b]; }
+			}
+
+			// ---- phase 2: one task per 6 x 6 block (diagonal blocks also own their camera's J^T r slice)
+			const int ndiag = nr_img, noff = (int)block_pairs.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads())
+			for (int task = 0; task < ndiag + noff; ++task) {
+				if (task < ndiag) {
+					const int c = task;
+					double L[6][6] = {{0}}, g[6] = {0, 0, 0, 0, 0, 0};
+					for (int q : cam_pairs[c]) {
+						const MatchPair& pair = match_pairs[q];
+						const int from = index_map[pair.from], to = index_map[pair.to];
+						const int nm = (int)pair.m.match.size();
+						const double* row = deriv.data() + (size_t)match_cnt_prefix_sum[q] * 24;
+						const double* res = residual.data() + (size_t)match_cnt_prefix_sum[q] * 2;
+						// a pair from a camera to itself does not occur (add_match is called for i != j); the
+						// offsets below are the local indices the reference's 12 x 12 block gives this camera
+						const int o = from == c ? 0 : 6;
+						(void)to;
+						for (int k = 0; k < nm; ++k, row += 24, res += 2) {
+							const double* dx = row + o; const double* dy = row + 12 + o;
+							const double rx = res[0], ry = res[1];
+							for (int a = 0; a < 6; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
+							for (int a = 0; a < 6; ++a)
+								for (int b = a; b < 6; ++b) L[a][b] += dx[a] * dx[b] + dy[a] * dy[b];
+						}
+					}
+					const int base = c * NR_PARAM_PER_CAMERA;
+					for (int a = 0; a < 6; ++a) {
+						Jtr[base + a] = g[a];
+						for (int b = a; b < 6; ++b) { JtJ[(size_t)(base + a) * np + base + b] = L[a][b]; JtJ[(size_t)(base + b) * np + base + a] = L[a][b]; }
+					}
+				} else {
+					const auto& blk = block_pairs[task - ndiag];
+					const int ci = blk.first.first, cj = blk.first.second;          // ci < cj
+					double L[6][6] = {{0}};                                          // L[p][q]: entry (param p of ci, param q of cj)
+					for (int q : blk.second) {
+						const MatchPair& pair = match_pairs[q];
+						const int from = index_map[pair.from];
+						const int nm = (int)pair.m.match.size();
+						const double* row = deriv.data() + (size_t)match_cnt_prefix_sum[q] * 24;
+						if (from == ci) {            // local (a, b) = (p, 6 + q'): dx[p] * dx[6 + q'] + dy[p] * dy[6 + q']
+							for (int k = 0; k < nm; ++k, row += 24) {
+								const double* dx = row; const double* dy = row + 12;
+								for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) L[a][b] += dx[a] * dx[6 + b] + dy[a] * dy[6 + b];
+							}
+						} else {                     // from == cj: local (a, b) = (q', 6 + p): dx[q'] * dx[6 + p] + dy[q'] * dy[6 + p]
+							for (int k = 0; k < nm; ++k, row += 24) {
+								const double* dx = row; const double* dy = row + 12;
+								for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) L[a][b] += dx[b] * dx[6 + a] + dy[b] * dy[6 + a];
+							}
+						}
+					}
+					const int bi = ci * NR_PARAM_PER_CAMERA, bj = cj * NR_PARAM_PER_CAMERA;
+					for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
+						JtJ[(size_t)(bi + a) * np + bj + b] = L[a][b];
+						JtJ[(size_t)(bj + b) * np + bi + a] = L[a][b];
+					}
 				}
 			}
 		}
@@ -471,6 +577,11 @@ class CameraEstimator {
 				iba.optimize();
 			}
 			if (config::STRAIGHTEN) Camera::straighten(cameras);
+			if (std::getenv("PANO_BA_PROFILE")) {
+				const BaProfile& bp = ba_prof();
+				std::fprintf(stderr, "[pano BA] optimize calls %ld, LM iterations %ld: error %.1f ms, jacobian %.1f ms, solve %.1f ms\n",
+						bp.n_opt, bp.n_iter, bp.t_err * 1e3, bp.t_jac * 1e3, bp.t_solve * 1e3);
+			}
 			return cameras;
 		}
 
