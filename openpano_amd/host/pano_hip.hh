@@ -43,6 +43,7 @@
 #include "stitch/homography.hh"
 #include "stitch/imageref.hh"
 #include "stitch/stitcher_image.hh"
+#include "lib/debugutils.hh"
 #else
 #include "pano_types.hh"
 #include "pano_camera.hh"
@@ -444,6 +445,13 @@ inline Mat32f hip_blend(const Bundle& b, bool crop = false) {
 	g.proj_min[0] = b.proj_range.min.x; g.proj_min[1] = b.proj_range.min.y;
 	g.proj_max[0] = b.proj_range.max.x; g.proj_max[1] = b.proj_range.max.y;
 	g.resolution[0] = res.x; g.resolution[1] = res.y;
+#ifdef OPENPANO_WITH_REFERENCE
+	{	// the line ConnectedImages::blend prints (stitcher_image.cc:121-124); the reference's run_test.py scrapes it
+		const Vec2D size_d = b.proj_range.size() / res;
+		const Coor size(size_d.x, size_d.y);
+		print_debug("Final Image Size: (%d, %d)\n", size.x, size.y);
+	}
+#endif
 	std::vector<op_blend_image> ims(n);
 	for (int i = 0; i < n; ++i) {
 		auto& c = b.component[i];

@@ -99,6 +99,8 @@ int ref_config_set(const char* key, float v) {
 }
 
 void ref_set_threads(int n) { omp_set_num_threads(n); }
+// seed every TransformEstimation::get_transform of this library draws from now on (the random_device seam above)
+void ref_set_seed(unsigned seed) { g_ref_seed = seed; }
 
 // ---- staged SIFT run (body of SIFTDetector::do_detect_feature, feature.cc:31-47,
 //      with every intermediate kept) ----

@@ -1,0 +1,116 @@
+// oracle/ref_stitch_test.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// The drop-in proven on the reference's OWN orchestration: Stitcher::build() (stitch/stitcher.cc:32-64)
+// and CylinderStitcher::build() (stitch/cylstitcher.cc:20-29) are compiled twice from the reference
+// sources by oracle/apply_hooks.py --
+//   Exact*   the reference path on the CPU (its SIFTDetector, TransformEstimation, CylinderWarper,
+//            ConnectedImages::blend, CameraEstimator), made deterministic: exact FeatureMatcher
+//            instead of the FLANN forest, injected mt19937 seed;
+//   Hooked*  the same files with INTEGRATION.md's five construction-site edits, i.e. the HIP library
+//            behind the reference's loops --
+// and run on the same image files in one process.  Compared: the "Final Image Size" of
+// stitcher_image.cc:124 (canvas dimensions) and every pixel of the panorama (<= 1e-4, north_star).
+//   ref_stitch_test <cylinder|camera|camera_ordered|trans> <seed> <multiband> img0.png img1.png ...
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <omp.h>
+
+#include "exact/stitcher.hh"
+#include "exact/cylstitcher.hh"
+#include "hip/stitcher.hh"
+#include "hip/cylstitcher.hh"
+#include "lib/imgproc.hh"
+
+using namespace pano;
+
+extern "C" {
+int ref_config_set(const char* key, float v);
+void ref_set_seed(unsigned seed);
+void ref_set_threads(int n);
+}
+
+static void set_local(const std::string& k, float v) {
+	using namespace config;
+#define CFG(x) if (k == #x) { x = v; return; }
+	CFG(CYLINDER) CFG(TRANS) CFG(ESTIMATE_CAMERA) CFG(ORDERED_INPUT) CFG(CROP) CFG(STRAIGHTEN)
+	CFG(FOCAL_LENGTH) CFG(MAX_OUTPUT_SIZE) CFG(LAZY_READ) CFG(SIFT_WORKING_SIZE) CFG(NUM_OCTAVE)
+	CFG(NUM_SCALE) CFG(SCALE_FACTOR) CFG(GAUSS_SIGMA) CFG(GAUSS_WINDOW_FACTOR)
+	CFG(JUDGE_EXTREMA_DIFF_THRES) CFG(CONTRAST_THRES) CFG(PRE_COLOR_THRES) CFG(EDGE_RATIO)
+	CFG(CALC_OFFSET_DEPTH) CFG(OFFSET_THRES) CFG(ORI_RADIUS) CFG(ORI_HIST_SMOOTH_COUNT)
+	CFG(DESC_HIST_SCALE_FACTOR) CFG(DESC_INT_FACTOR) CFG(MATCH_REJECT_NEXT_RATIO)
+	CFG(RANSAC_ITERATIONS) CFG(RANSAC_INLIER_THRES) CFG(INLIER_IN_MATCH_RATIO)
+	CFG(INLIER_IN_POINTS_RATIO) CFG(SLOPE_PLAIN) CFG(LM_LAMBDA) CFG(MULTIPASS_BA) CFG(MULTIBAND)
+#undef CFG
+}
+// libopenpano_ref.so is linked -Bsymbolic (the RNG seam needs it) and keeps its own copy of the
+// config:: globals; the orchestration variants compiled into this executable read the executable's
+static void set_both(const char* k, float v) {
+	if (ref_config_set(k, v) != 0) { printf("unknown config key %s\n", k); exit(2); }
+	set_local(k, v);
+}
+
+int main(int argc, char** argv) {
+	if (argc < 6) { printf("usage: ref_stitch_test <cylinder|camera|camera_ordered|trans> <seed> <multiband> img0 img1 ...\n"); return 2; }
+	const std::string mode = argv[1];
+	const unsigned seed = (unsigned)atol(argv[2]);
+	const int multiband = atoi(argv[3]);
+	std::vector<std::string> files(argv + 4, argv + argc);
+	// src/config.cfg defaults, through the same float narrowing as init_config (main.cc:237-292)
+	const struct { const char* k; float v; } kv[] = {
+		{"CYLINDER", 0}, {"ESTIMATE_CAMERA", 1}, {"TRANS", 0}, {"ORDERED_INPUT", 0}, {"CROP", 1}, {"MAX_OUTPUT_SIZE", 8000},
+		{"LAZY_READ", 0}, {"FOCAL_LENGTH", 37}, {"SIFT_WORKING_SIZE", 800}, {"NUM_OCTAVE", 4}, {"NUM_SCALE", 7},
+		{"SCALE_FACTOR", 1.4142135623f}, {"GAUSS_SIGMA", 1.4142135623f}, {"GAUSS_WINDOW_FACTOR", 6}, {"CONTRAST_THRES", 4e-2f},
+		{"JUDGE_EXTREMA_DIFF_THRES", 2e-3f}, {"EDGE_RATIO", 6}, {"PRE_COLOR_THRES", 5e-2f}, {"CALC_OFFSET_DEPTH", 4},
+		{"OFFSET_THRES", 0.5f}, {"ORI_RADIUS", 4.5f}, {"ORI_HIST_SMOOTH_COUNT", 2}, {"DESC_HIST_SCALE_FACTOR", 3},
+		{"DESC_INT_FACTOR", 512}, {"MATCH_REJECT_NEXT_RATIO", 0.8f}, {"RANSAC_ITERATIONS", 1500}, {"RANSAC_INLIER_THRES", 3.5f},
+		{"INLIER_IN_MATCH_RATIO", 0.1f}, {"INLIER_IN_POINTS_RATIO", 0.04f}, {"STRAIGHTEN", 1}, {"SLOPE_PLAIN", 8e-3f},
+		{"LM_LAMBDA", 5}, {"MULTIPASS_BA", 1}, {"MULTIBAND", 0}};
+	for (auto& e : kv) set_both(e.k, e.v);
+	bool cyl = false;
+	if (mode == "cylinder") { cyl = true; set_both("CYLINDER", 1); set_both("ESTIMATE_CAMERA", 0); set_both("ORDERED_INPUT", 1); }   // main.cc: CYLINDER implies ordered input
+	else if (mode == "camera") { }
+	else if (mode == "camera_ordered") { set_both("ORDERED_INPUT", 1); }
+	else if (mode == "trans") { set_both("TRANS", 1); set_both("ESTIMATE_CAMERA", 0); set_both("ORDERED_INPUT", 1); }
+	else { printf("unknown mode %s\n", mode.c_str()); return 2; }
+	set_both("MULTIBAND", (float)multiband);
+	// one thread: the reference's keypoint / match orders are thread-timing dependent (extrema.cc:56)
+	omp_set_num_threads(1); ref_set_threads(1);
+	ref_set_seed(seed);
+	HipTransformEstimation::seed_injected() = true; HipTransformEstimation::injected_seed() = seed;
+
+	printf("[reference orchestration, CPU, %zu images, mode %s]\n", files.size(), mode.c_str()); fflush(stdout);
+	Mat32f want = cyl ? ExactCylinderStitcher(files).build() : ExactStitcher(files).build();
+	printf("[reference orchestration + the five hooks -> libopenpano_hip.so]\n"); fflush(stdout);
+	Mat32f got = cyl ? HookedCylinderStitcher(files).build() : HookedStitcher(files).build();
+
+	int fail = 0;
+	printf("FINAL_SIZE reference %dx%d hooked %dx%d\n", want.width(), want.height(), got.width(), got.height());
+	if (want.rows() != got.rows() || want.cols() != got.cols()) { printf("FAIL: canvas size differs\n"); return 1; }
+	const long n = (long)want.rows() * want.cols();
+	long mask_diff = 0, exact = 0, valid = 0; double maxd = 0;
+	for (long e = 0; e < n; ++e) {
+		const float* p = want.ptr() + e * 3; const float* q = got.ptr() + e * 3;
+		const bool na = p[0] < 0, nb = q[0] < 0;
+		if (na != nb) { ++mask_diff; continue; }
+		if (na) continue;
+		++valid;
+		bool eq = true;
+		for (int c = 0; c < 3; ++c) { maxd = std::max(maxd, (double)fabsf(p[c] - q[c])); eq &= (p[c] == q[c]); }
+		exact += eq;
+	}
+	printf("PANORAMA covered %.1f%%, max |diff| %.3g, bit-equal %.4f%%, no-pixel mask flips %ld\n", 100.0 * valid / n, maxd,
+			100.0 * exact / std::max(1L, valid), mask_diff);
+	if (!(maxd <= 1e-4)) { printf("FAIL: max diff %g > 1e-4\n", maxd); ++fail; }
+	if (mask_diff > n / 20000 + 2) { printf("FAIL: %ld mask flips\n", mask_diff); ++fail; }
+	if (valid < n / 4) { printf("FAIL: canvas barely covered\n"); ++fail; }
+	// main.cc:226-229: crop under config CROP -- same rectangle from both
+	Mat32f cw = crop(want), cg = crop(got);
+	printf("CROPPED reference %dx%d hooked %dx%d\n", cw.width(), cw.height(), cg.width(), cg.height());
+	if (cw.rows() != cg.rows() || cw.cols() != cg.cols()) { printf("FAIL: crop rectangle differs\n"); ++fail; }
+	printf(fail ? "STITCH DROPIN FAILED\n" : "STITCH DROPIN OK\n");
+	return fail ? 1 : 0;
+}

@@ -176,3 +176,40 @@ def test_reference_dropin():
     r = subprocess.run([DROPIN], capture_output=True, text=True, env=_env(), timeout=600, cwd=os.path.dirname(DROPIN))
     print(r.stdout[-4000:])
     assert r.returncode == 0 and "DROPIN OK" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+STITCH_DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_stitch_test")
+STITCH_CASES = [
+    # (id, mode, multiband, natural-config, number of views): BASELINE config 1 is the 2-view CYLINDER job
+    ("config1_cylinder_2x600x400", "cylinder", 0, 1, 2),
+    ("cylinder_4x600x400", "cylinder", 0, 2, 4),            # > 2 views: the h-factor search of update_h_factor
+    ("config2_camera_11x600x400", "camera_ordered", 0, 2, 11),
+    ("camera_unordered_multiband_5x600x400", "camera", 3, 2, 5),
+    ("trans_3x600x400", "trans", 0, 2, 3),
+]
+
+
+@pytest.mark.parametrize("name,mode,mb,cfgk,n", STITCH_CASES, ids=[c[0] for c in STITCH_CASES])
+def test_reference_orchestration_dropin(tmp_path, name, mode, mb, cfgk, n):
+    """The reference's OWN Stitcher::build() / CylinderStitcher::build() (compiled from its sources) against
+    the same files with INTEGRATION.md's five hooks applied by oracle/apply_hooks.py, on natural-texture
+    PNG inputs: identical canvas size ("Final Image Size", stitcher_image.cc:124), identical crop
+    rectangle, panorama within 1e-4."""
+    import natural
+    if not os.path.exists(STITCH_DROPIN):
+        pytest.skip("oracle/_ref/ref_stitch_test not built (reference sources absent at build time)")
+    if not natural.available():
+        pytest.skip("tests/golden/natural or PIL missing")
+    from PIL import Image
+    files = []
+    for k, v in enumerate(natural.config_views(cfgk, n)):
+        p = str(tmp_path / f"{k:02d}.png")
+        Image.fromarray(v).save(p)
+        files.append(p)
+    r = subprocess.run([STITCH_DROPIN, mode, "38", str(mb)] + files, capture_output=True, text=True, env=_env(), timeout=900,
+                       cwd=os.path.dirname(STITCH_DROPIN))
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "STITCH DROPIN OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    # both builds printed the line the reference's own run_test.py scrapes, with the same size
+    sizes = [ln.split("Final Image Size:")[1].strip() for ln in r.stderr.splitlines() if "Final Image Size:" in ln]
+    assert len(sizes) == 2 and sizes[0] == sizes[1], sizes
