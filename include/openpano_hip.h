@@ -222,6 +222,13 @@ typedef struct op_blend_image {
 	int on_device;
 	double homo_inv[9];   /* ImageComponent::homo_inv (stitch/stitcher_image.hh:40-42) */
 	double range[4];      /* ImageComponent::range: min.x, min.y, max.x, max.y (:48) */
+	/* Dimensions of the pixel buffer `data` when they differ from h / w, else 0.  The reference keeps
+	 * ImageRef::_width/_height from load() (stitch/imageref.hh:22-31) after CylinderStitcher replaced the
+	 * Mat by its cylinder warp (cylstitcher.cc:66-67): bounds, blend weights and the image centre keep
+	 * using the ORIGINAL size (blender.hh:39-44, blender.cc:31-35, stitcher_image.cc:150) while
+	 * interpolate() reads the warped Mat with its own rows/cols (lib/imgproc.cc:135-156).  h / w are the
+	 * ImageRef's, mat_h / mat_w the Mat's. */
+	int mat_h, mat_w;
 } op_blend_image;
 typedef struct op_blend_geom {
 	int proj_method;      /* ConnectedImages::ProjectionMethod (:30): 0 flat, 1 cylindrical, 2 spherical */

@@ -38,7 +38,8 @@ struct op_canvas {
 namespace {
 
 struct BlendImg {
-	const float* data; int h, w;
+	const float* data; int h, w;   // ImageRef::height()/width(): bounds, weights, centre
+	int mh, mw;                    // rows / cols of the pixel buffer (differ after a cylinder pre-warp, see op_blend_image)
 	int x0, y0, x1, y1;        // ROI on the canvas, inclusive (BlenderBase::Range, blender.hh:19-27)
 	double hinv[9];
 	long long roi_off;         // multiband: offset (pixels) of this image's ROI planes
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, const BlendIm
 		if (ox < 0 || ox >= im.w || oy < 0 || oy >= im.h) continue;      // ImageToAdd::map_coor (blender.hh:39-44)
 		const float r = (float)oy, c = (float)ox;
 		float col[3];
-		if (!interpolate(im.data, im.h, im.w, r, c, col)) continue;
+		if (!interpolate(im.data, im.mh, im.mw, r, c, col)) continue;
 		if (col[0] < 0) continue;
 		float w = (float)(0.5 - fabs((double)(c / (float)im.w) - 0.5));
 		if (!ordered_input) w = (float)((double)w * (0.5 - fabs((double)(r / (float)im.h) - 0.5)));
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) k_mb_first_level(BlendGeom g, const Blend
 	proj2homo(g.method, cx, cy, hx, hy, hz);
 	space_to_image(im, hx, hy, hz, ox, oy);
 	float col[3];
-	bool ok = interpolate(im.data, im.h, im.w, (float)oy, (float)ox, col);
+	bool ok = interpolate(im.data, im.mh, im.mw, (float)oy, (float)ox, col);
 	if (ok) { float mn = fminf(col[0], fminf(col[1], col[2])); if (mn < 0) ok = false; }
 	float4 px;
 	if (!ok) { px = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -563,11 +564,13 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		if (!s.data || s.h < 2 || s.w < 2) OP_FAIL(OP_ERR_INVALID, "op_blend: bad image " + std::to_string(k));
 		BlendImg& b = h_imgs[k];
 		b.h = s.h; b.w = s.w;
+		b.mh = s.mat_h > 0 ? s.mat_h : s.h; b.mw = s.mat_w > 0 ? s.mat_w : s.w;
+		if (b.mh < 2 || b.mw < 2) OP_FAIL(OP_ERR_INVALID, "op_blend: bad pixel buffer size of image " + std::to_string(k));
 		if (s.on_device) b.data = s.data;
 		else {
 			float* d = nullptr;
-			HIPCHK(pool_alloc((void**)&d, sizeof(float) * 3 * (size_t)s.h * s.w)); fr.v.push_back(d);
-			HIPCHK(hipMemcpyAsync(d, s.data, sizeof(float) * 3 * (size_t)s.h * s.w, hipMemcpyHostToDevice, st));
+			HIPCHK(pool_alloc((void**)&d, sizeof(float) * 3 * (size_t)b.mh * b.mw)); fr.v.push_back(d);
+			HIPCHK(hipMemcpyAsync(d, s.data, sizeof(float) * 3 * (size_t)b.mh * b.mw, hipMemcpyHostToDevice, st));
 			b.data = d;
 		}
 		int roi[4]; roi_of(g, s.range, roi);

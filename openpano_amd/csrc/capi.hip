@@ -178,7 +178,7 @@ int op_ctx_profile_get(op_ctx* c, int i, const char** label, double* total_ms, l
 }
 
 const char* op_last_error(void) { return g_last_error.c_str(); }
-int op_abi_version(void) { return 2; }
+int op_abi_version(void) { return 3; }      // 3: op_blend_image.mat_h / mat_w
 
 void op_config_default(op_config* c) {
 	// src/config.cfg (every literal goes through a float, lib/config.cc:19-26)

@@ -54,7 +54,7 @@ OP_F32, OP_U8 = 0, 1
 
 class OpBlendImage(C.Structure):
     _fields_ = [("data", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("on_device", C.c_int),
-                ("homo_inv", C.c_double * 9), ("range", C.c_double * 4)]
+                ("homo_inv", C.c_double * 9), ("range", C.c_double * 4), ("mat_h", C.c_int), ("mat_w", C.c_int)]
 
 
 class OpBlendGeom(C.Structure):

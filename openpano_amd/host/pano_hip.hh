@@ -457,6 +457,7 @@ inline Mat32f hip_blend(const Bundle& b, bool crop = false) {
 		auto& c = b.component[i];
 		c.imgptr->load();
 		ims[i].data = c.imgptr->img->ptr(); ims[i].h = c.imgptr->height(); ims[i].w = c.imgptr->width(); ims[i].on_device = 0;
+		ims[i].mat_h = c.imgptr->img->height(); ims[i].mat_w = c.imgptr->img->width();      // != h / w after a cylinder pre-warp (op_blend_image)
 		for (int k = 0; k < 9; ++k) ims[i].homo_inv[k] = c.homo_inv[k];
 		ims[i].range[0] = c.range.min.x; ims[i].range[1] = c.range.min.y; ims[i].range[2] = c.range.max.x; ims[i].range[3] = c.range.max.y;
 	}
