@@ -178,6 +178,27 @@ int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npa
 void op_matches_free(op_matches* m);
 
 /* =====================================================================================
+ * SEVERAL GPUs IN ONE PROCESS -- SURVEY 8(e): the reference's two parallel loops are the axes
+ * (images: stitch/stitcherbase.cc:14-25; image pairs: stitch/stitcher.cc:96-113).  A group owns
+ * one context (stream, workspaces, one host thread per call) per listed device.  The *_multi calls
+ * return exactly what the single-device calls return; with one device they ARE those calls.
+ * (One process per GPU with an RCCL all-gather instead: openpano_amd/distributed.py.)
+ * ===================================================================================== */
+typedef struct op_group op_group;
+int op_group_create(const int* devices, int ndev, op_group** out);   /* a device may be listed twice */
+void op_group_destroy(op_group* g);
+int op_group_size(const op_group* g);
+op_ctx* op_group_ctx(op_group* g, int k);                             /* context k; context 0 holds gathered results */
+/* StitcherBase::calc_feature sharded by image: image i runs on context i % ndev; the features are
+ * gathered (device-to-device over xGMI) into ONE op_features on context 0.  Host images only, or
+ * device images resident on the device of the context that owns them. */
+int op_sift_batch_multi(op_group* g, const op_config* cfg, const op_image* imgs, int n, op_features** out);
+/* Stitcher::pairwise_match sharded by pair: the feature table is replicated to every device (the
+ * descriptor all-gather of SURVEY 8(e).2), the pair list is dealt balanced by K_i * K_j, the per-pair
+ * lists come back in the order of `pairs`. */
+int op_match_pairs_multi(op_group* g, const op_config* cfg, const op_features* f, const int* pairs, int npairs, op_matches** out);
+
+/* =====================================================================================
  * RANSAC -- replaces TransformEstimation(...).get_transform(MatchInfo*)
  * (stitch/transform_estimate.hh:22-31, transform_estimate.cc:26-218) for every pair at once.
  * pairs / m must be the pair list and result of op_match_pairs (match p belongs to pairs[p]);

@@ -31,6 +31,17 @@ struct op_matches {
 
 const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p) { return m->pairs[p]; }
 int op_matches_num_pairs(const op_matches* m) { return m->npairs; }
+// multi.hip: parts[k] holds the pairs index[k][0..] of the job's pair list -> one op_matches in job order
+op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::vector<int>>& index, int npairs) {
+	op_matches* m = new op_matches;
+	m->npairs = npairs; m->pairs.resize(npairs);
+	for (size_t k = 0; k < index.size(); ++k)
+		for (size_t q = 0; q < index[k].size(); ++q) {
+			m->pairs[index[k][q]] = std::move(parts[k]->pairs[q]);
+			m->total += (int64_t)(m->pairs[index[k][q]].size() / 2);
+		}
+	return m;
+}
 
 namespace {
 

@@ -458,6 +458,57 @@ int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* co
 	return OP_OK;
 }
 
+}	// extern "C"
+
+// device-to-device copy between two contexts' devices, ordered on dst's stream (xGMI peer copy when the
+// devices differ; multi.hip enables direct peer access where the hardware allows it)
+static hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
+	if (!bytes) return hipSuccess;
+	if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+	return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+
+// multi.hip: image i of the job lives in parts[i % nparts] at local index i / nparts -> one table on dst's device
+int op_features_gather_sharded(op_ctx* dst, op_features* const* parts, int nparts, int n, op_features** out) {
+	HIPCHK(hipSetDevice(dst->device));
+	op_features* f = new op_features;
+	f->n = n; f->counts.assign(n, 0); f->offsets.assign(n + 1, 0); f->device = dst->device;
+	int64_t total = 0;
+	for (int i = 0; i < n; ++i) { f->counts[i] = parts[i % nparts]->counts[i / nparts]; f->offsets[i] = total; total += f->counts[i]; }
+	f->offsets[n] = total;
+	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
+	HIPCHK(pool_alloc((void**)&f->desc, sizeof(float) * 128 * cnt));
+	HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt));
+	HIPCHK(pool_alloc((void**)&f->real, sizeof(double) * 2 * cnt));
+	for (int i = 0; i < n; ++i) {
+		const op_features* p = parts[i % nparts]; const int li = i / nparts; const size_t c = (size_t)f->counts[i];
+		HIPCHK(copy_between(f->desc + f->offsets[i] * 128, dst->device, p->desc + p->offsets[li] * 128, p->device, sizeof(float) * 128 * c, dst->stream));
+		HIPCHK(copy_between(f->coor + f->offsets[i] * 2, dst->device, p->coor + p->offsets[li] * 2, p->device, sizeof(double) * 2 * c, dst->stream));
+		HIPCHK(copy_between(f->real + f->offsets[i] * 2, dst->device, p->real + p->offsets[li] * 2, p->device, sizeof(double) * 2 * c, dst->stream));
+	}
+	HIPCHK(hipStreamSynchronize(dst->stream));
+	*out = f;
+	return OP_OK;
+}
+
+// multi.hip: the whole table of f on dst's device (the all-gather step of SURVEY 8(e).2 as one peer copy per array)
+int op_features_replicate(op_ctx* dst, const op_features* src, op_features** out) {
+	HIPCHK(hipSetDevice(dst->device));
+	op_features* f = new op_features;
+	f->n = src->n; f->counts = src->counts; f->offsets = src->offsets; f->device = dst->device; f->has_desc = src->has_desc;
+	const int64_t total = src->offsets[src->n];
+	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
+	HIPCHK(pool_alloc((void**)&f->desc, src->has_desc ? sizeof(float) * 128 * cnt : sizeof(float)));
+	HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt));
+	if (src->has_desc) HIPCHK(copy_between(f->desc, dst->device, src->desc, src->device, sizeof(float) * 128 * (size_t)total, dst->stream));
+	HIPCHK(copy_between(f->coor, dst->device, src->coor, src->device, sizeof(double) * 2 * (size_t)total, dst->stream));
+	HIPCHK(hipStreamSynchronize(dst->stream));
+	*out = f;
+	return OP_OK;
+}
+
+extern "C" {
+
 void op_features_free(op_features* f) {
 	if (!f) return;
 	hipSetDevice(f->device);

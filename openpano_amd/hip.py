@@ -145,6 +145,13 @@ def lib():
         L.op_matches_total.restype = C.c_int64
         L.op_matches_total.argtypes = [C.c_void_p]
         L.op_matches_free.argtypes = [C.c_void_p]
+    L.op_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_group_destroy.argtypes = [C.c_void_p]
+    L.op_group_size.argtypes = [C.c_void_p]
+    L.op_group_ctx.restype = C.c_void_p
+    L.op_group_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.op_sift_batch_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_match_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.op_matches_from_host.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_ransac_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -212,6 +219,55 @@ class Context:
     def close(self):
         if self.handle:
             lib().op_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BorrowedContext(Context):
+    """a context owned by an op_group (never destroyed from Python)"""
+
+    def __init__(self, handle, device):
+        self.handle = C.c_void_p(handle)
+        self.device = device
+
+    def close(self):
+        self.handle = C.c_void_p()
+
+
+class Group:
+    """``op_group``: several GPUs driven from this process; a device may be listed twice."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self.handle = C.c_void_p()
+        check(lib().op_group_create(devs, len(devices), C.byref(self.handle)))
+        self.devices = list(devices)
+        self.ctx0 = _BorrowedContext(lib().op_group_ctx(self.handle, 0), devices[0])
+
+    def sift_batch(self, cfg, images) -> "Features":
+        arr, keep = _mk_images(images)
+        ccfg = OpConfig.from_config(cfg)
+        h = C.c_void_p()
+        check(lib().op_sift_batch_multi(self.handle, C.byref(ccfg), arr, len(images), C.byref(h)))
+        del keep
+        return Features(self.ctx0, h)
+
+    def match_pairs_handle(self, cfg, feats, pairs) -> "Matches":
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        ccfg = OpConfig.from_config(cfg)
+        h = C.c_void_p()
+        check(lib().op_match_pairs_multi(self.handle, C.byref(ccfg), feats.handle, pr.ctypes.data_as(C.c_void_p), len(pr), C.byref(h)))
+        return Matches(h, len(pr))
+
+    def close(self):
+        if self.handle:
+            self.ctx0.close()
+            lib().op_group_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

@@ -89,7 +89,31 @@ class HipContext {
 			return c.ctx;
 		}
 		static int& device() { static int d = 0; return d; }     // set before first use to pick a GPU
+		// Several GPUs in this process: set_devices({0, 1, ...}) -- or OPENPANO_DEVICES=0,1,... in
+		// the environment -- makes the batched adapters (HipSIFTDetector::calc_feature, HipPairWiseMatcher)
+		// shard their image / pair loops over the listed devices; results land on the first one.
+		static void set_devices(const std::vector<int>& devs) {
+			if (group_slot()) { op_group_destroy(group_slot()); group_slot() = nullptr; }
+			if (devs.size() > 1) PANO_HIP_CHECK(op_group_create(devs.data(), (int)devs.size(), &group_slot()));
+			if (!devs.empty()) device() = devs[0];
+			group_env_done() = true;
+		}
+		static op_group* group() {
+			if (!group_env_done()) {
+				group_env_done() = true;
+				if (const char* e = std::getenv("OPENPANO_DEVICES")) {
+					std::vector<int> devs;
+					for (const char* p = e; *p;) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+					set_devices(devs);
+				}
+			}
+			return group_slot();
+		}
+		// the context that owns gathered results: context 0 of the group, else this thread's own
+		static op_ctx* home() { return group() ? op_group_ctx(group(), 0) : get(); }
 	private:
+		static op_group*& group_slot() { static op_group* g = nullptr; return g; }
+		static bool& group_env_done() { static bool b = false; return b; }
 		op_ctx* ctx = nullptr;
 		HipContext() { PANO_HIP_CHECK(op_ctx_create(device(), nullptr, &ctx)); }
 		~HipContext() { op_ctx_destroy(ctx); }
@@ -169,7 +193,11 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 			std::vector<op_image> ims;
 			for (auto* m : imgs) ims.push_back(op_image{m->ptr(), m->rows(), m->cols(), 0, OP_F32});
 			HipFeatureSet fs;
-			PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, ims.data(), (int)ims.size(), &fs.handle));
+			if (op_group* g = HipContext::group()) {        // images dealt over the group's GPUs, features gathered on its first
+				PANO_HIP_CHECK(op_sift_batch_multi(g, &cfg, ims.data(), (int)ims.size(), &fs.handle));
+				ctx = op_group_ctx(g, 0);
+			} else
+				PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, ims.data(), (int)ims.size(), &fs.handle));
 			fs.feats.resize(imgs.size());
 			for (size_t k = 0; k < imgs.size(); ++k) {
 				const int n = op_features_count(fs.handle, (int)k);
@@ -247,7 +275,7 @@ class HipPairWiseMatcher {
 				}
 				dp[k] = flat[k].data(); cp[k] = coor[k].data();
 			}
-			PANO_HIP_CHECK(op_features_from_host(HipContext::get(), dp.data(), cp.data(), counts.data(), n, &handle));
+			PANO_HIP_CHECK(op_features_from_host(HipContext::home(), dp.data(), cp.data(), counts.data(), n, &handle));
 		}
 		void precompute_default() const {
 			const int n = (int)feats.size();
@@ -262,7 +290,10 @@ class HipPairWiseMatcher {
 			for (auto& t : tasks) { pr.push_back(t.first); pr.push_back(t.second); }
 			const op_config cfg = hip_config_snapshot();
 			op_matches* m = nullptr;
-			PANO_HIP_CHECK(op_match_pairs(HipContext::get(), &cfg, handle, pr.data(), (int)tasks.size(), &m));
+			if (op_group* g = HipContext::group())          // pair list dealt over the group's GPUs (K_i * K_j balanced)
+				PANO_HIP_CHECK(op_match_pairs_multi(g, &cfg, handle, pr.data(), (int)tasks.size(), &m));
+			else
+				PANO_HIP_CHECK(op_match_pairs(HipContext::get(), &cfg, handle, pr.data(), (int)tasks.size(), &m));
 			for (size_t p = 0; p < tasks.size(); ++p) {
 				const int c = op_matches_count(m, (int)p);
 				std::vector<int> idx((size_t)c * 2 + 2);
