@@ -17,23 +17,56 @@
 //       a contribution's rank inside its bin is the popcount of that mask below the lane, bin
 //       offsets are a 128-entry scan of the mask popcounts; the values land bin-major in LDS,
 //       in sample order inside each bin;
-//   3   lane L owns bins 2L and 2L+1 and adds their segments in order to its two fp32
+//   3   lane L owns bins L and L+64 and adds their segments in order to its two fp32
 //       accumulators -- every bin sees exactly the reference's sequence of additions.
+// The window is not scanned whole: per window column only the rows that can pass the circle and
+// rotated-square tests are enumerated (a conservative interval), the exact tests decide.
 #include "internal.hpp"
 #include "devmath.hpp"
+#ifndef OP_DESC_EXPERIMENT
+#define OP_DESC_EXPERIMENT 0
+#endif
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int QCAP = 128;            // survivor queue (power of two, >= 2 x 64)
+constexpr int COLCAP = 2048;         // candidate samples of one keypoint in the column-interval enumeration
 
 struct DescLds {
 	unsigned long long mask[128];    // per bin: bit l = lane l's sample of the current batch contributes
-	float sorted[512];               // the batch's contributions, bin-major, sample order inside a bin
+	float sorted[512 + 3 * 128 + 64] __attribute__((aligned(16)));   // the batch's contributions, bin-major, sample order inside a bin; every list starts on a 16-byte boundary and is zero-padded to a multiple of 4
 	unsigned short off[128];         // first slot of every bin in sorted[]
 	float hist[128];
 	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates
 	float q_xr[QCAP], q_yr[QCAP];
+	uint64_t exptab[32];             // glibc's exp2f table (devmath.hpp), staged once per workgroup
+	short col_lo[64], col_start[64]; // column c of the window: first candidate row, index of its first candidate
+	unsigned char colmap[COLCAP];    // candidate index -> window column
 };
+
+// Wave64 inclusive add-scan and max-reduction on the VALU data-parallel primitives (row_shr within the
+// four rows of 16 lanes, then row_bcast:15 / row_bcast:31 across rows): a dozen VALU instructions instead
+// of six ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ int wave_scan_add(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
+	return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {                        // v >= 0
+	int t;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+	return __builtin_amdgcn_readlane(v, 63);
+}
 
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
 		const long long* img_offset, long long cap, float* desc, double* coor, double* real) {
@@ -43,6 +76,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 	const float pi2 = (float)(2 * 3.14159265358979323846);
 	const float nbin_per_rad = 8 / pi2;
 	S.mask[2 * lane] = 0ULL; S.mask[2 * lane + 1] = 0ULL;
+	if (lane < 32) S.exptab[lane] = opdev::kExp2fTab[lane];
 	__syncthreads();
 
 	long long total = img_offset[p.n];                 // device-side count (k_image_offsets)
@@ -58,13 +92,63 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		const float* g_img = base + plane_off_gauss(od, p.nscale, kp.scale);
 		const float ort = kp.dir;
 		const float hist_w = kp.sf * (float)p.desc_scale_factor;
+		// x / hist_w for the two rotated coordinates of every window sample: (float)((double)x * rd) with
+		// rd = 1 / (double)hist_w is the correctly rounded fp32 quotient (the double product is within 2^-52
+		// of x / hist_w, and a quotient of two fp32 numbers is never closer than 2^-49 (relative) to a
+		// rounding boundary of fp32), at a third of the instructions of an IEEE fp32 division
+		const double rd = 1.0 / (double)hist_w;
 		const float exp_denom = 2 * (4.f * 4.f);
 		const int radius = (int)round(0.70710678118654752440 * (double)hist_w * (4 + 1));
 		const float cosort = opdev::cosf_glibc(ort), sinort = opdev::sinf_glibc(ort);
 		const int side = 2 * radius + 1, nsamp = side * side;
 		const float fr2 = (float)radius * (float)radius;
-		float acc0 = 0.f, acc1 = 0.f;     // bins 2 * lane and 2 * lane + 1
+		float acc0 = 0.f, acc1 = 0.f;     // bins lane and lane + 64
 		int qhead = 0, qn = 0;            // survivor queue state (wave-uniform)
+
+		// ---- candidate enumeration.  The reference visits the whole (2 radius + 1)^2 window in (xx outer,
+		// yy inner) order and keeps a sample only inside the circle and the rotated 4 x 4 bin square
+		// (sift.cc:110-126) -- about a third of the window.  Each window column's rows that CAN pass are an
+		// interval, computed here with a safety margin of a row on either side; the exact float tests of
+		// the reference then run on those candidates only, in the reference's order.  Windows wider than 64
+		// columns or with more than COLCAP candidates (other DESC_HIST_SCALE_FACTORs) walk the full window.
+		int ncand = nsamp;
+		bool cols = side <= 64;
+		if (cols) {
+			int lo = 0, len = 0;
+			if (lane < side) {
+				const int xx = lane - radius;
+				const float fxx = (float)xx;
+				const int nowx = kp.x + xx;
+				float ylo = -(float)radius, yhi = (float)radius;
+				const float rem = fr2 - fxx * fxx;
+				const float yc = rem > 0.f ? sqrtf(rem) + 1.f : 1.f;
+				ylo = fmaxf(ylo, -yc); yhi = fminf(yhi, yc);
+				// -2.5 <= rot / hist_w <= 1.5 for both rotated coordinates (bin in [-1, 3] after the +1.5 shift)
+				const float m = 0.02f * hist_w + 0.25f;
+				const float blo = -2.5f * hist_w - m, bhi = 1.5f * hist_w + m;
+				if (fabsf(cosort) > 0.05f) {           // y_rot * hist_w = -xx sin + yy cos
+					const float a = (blo + fxx * sinort) / cosort, b = (bhi + fxx * sinort) / cosort;
+					ylo = fmaxf(ylo, fminf(a, b)); yhi = fminf(yhi, fmaxf(a, b));
+				}
+				if (fabsf(sinort) > 0.05f) {           // x_rot * hist_w = xx cos + yy sin
+					const float a = (blo - fxx * cosort) / sinort, b = (bhi - fxx * cosort) / sinort;
+					ylo = fmaxf(ylo, fminf(a, b)); yhi = fminf(yhi, fmaxf(a, b));
+				}
+				int ilo = (int)floorf(ylo) - 1, ihi = (int)ceilf(yhi) + 1;
+				ilo = ilo < -radius ? -radius : ilo; ihi = ihi > radius ? radius : ihi;
+				ilo = ilo < 1 - kp.y ? 1 - kp.y : ilo; ihi = ihi > h - 2 - kp.y ? h - 2 - kp.y : ihi;     // between(nowy, 1, h - 1)
+				if (nowx >= 1 && nowx <= w - 2 && ihi >= ilo) { lo = ilo; len = ihi - ilo + 1; }
+			}
+			const int incl = wave_scan_add(len);
+			ncand = __builtin_amdgcn_readlane(incl, 63);
+			cols = ncand <= COLCAP;
+			if (cols) {
+				const int start = incl - len;
+				S.col_lo[lane] = (short)lo; S.col_start[lane] = (short)start;
+				for (int k = 0; k < len; ++k) S.colmap[start + k] = (unsigned char)lane;
+			} else ncand = nsamp;
+			__syncthreads();
+		}
 
 		// phases 1b - 3 on one dense batch of queued survivors (window order preserved)
 		auto process_batch = [&](int n) {
@@ -79,9 +163,19 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
 				const float gdy = g_img[gi + w] - g_img[gi - w];
 				const float gdx = g_img[gi + 1] - g_img[gi - 1];
+#if OP_DESC_EXPERIMENT == 1       // timing experiment only: no transcendental twins
+				const float now_mag = gdx + gdy;
+				float now_ort = fabsf(gdy - gdx) + 3.f;
+				float weight = x_rot * 0.1f + 1.f;
+#elif OP_DESC_EXPERIMENT == 4     // timing experiment only: no gathers
+				const float now_mag = opdev::hypotf_glibc(x_rot, y_rot);
+				float now_ort = opdev::fast_atan_plus_pi(y_rot, x_rot);
+				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom, S.exptab);
+#else
 				const float now_mag = opdev::hypotf_glibc(gdx, gdy);
 				float now_ort = opdev::fast_atan_plus_pi(gdy, gdx);
-				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom);
+				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom, S.exptab);
+#endif
 				weight = weight * now_mag;
 				now_ort -= ort;
 				if (now_ort < 0) now_ort += pi2;
@@ -107,47 +201,91 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 					}
 				}
 			}
+#if OP_DESC_EXPERIMENT == 2       // timing experiment only: no ordering machinery
+			for (int c = 0; c < 8; ++c) { acc0 += val[c]; acc1 += (float)bin[c]; }
+			qhead = (qhead + n) & (QCAP - 1); qn -= n;
+			return;
+#endif
 			// phase 2: stable counting sort of the contributions by bin
+#if OP_DESC_EXPERIMENT == 5       // timing experiment only: plain stores instead of LDS atomics
+#pragma unroll
+			for (int c = 0; c < 8; ++c)
+				if (bin[c] >= 0) S.mask[bin[c]] = 1ULL << lane;
+#else
 #pragma unroll
 			for (int c = 0; c < 8; ++c)
 				if (bin[c] >= 0) atomicOr(&S.mask[bin[c]], 1ULL << lane);
+#endif
 			__syncthreads();
-			const unsigned long long m0 = S.mask[2 * lane], m1 = S.mask[2 * lane + 1];
-			const int c0 = __popcll(m0), c1 = __popcll(m1);
-			int incl = c0 + c1;                               // inclusive wave scan of the per-lane pair counts
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-			const int ex = incl - (c0 + c1);
-			S.off[2 * lane] = (unsigned short)ex; S.off[2 * lane + 1] = (unsigned short)(ex + c0);
+			{
+				const unsigned long long m0 = S.mask[2 * lane], m1 = S.mask[2 * lane + 1];
+				const int c0 = __popcll(m0), c1 = __popcll(m1);
+				const int p0 = (c0 + 3) & ~3, p1 = (c1 + 3) & ~3;         // list lengths rounded up to whole float4s
+				const int incl = wave_scan_add(p0 + p1);                   // inclusive wave scan of the per-lane pair sizes
+				const int ex = incl - (p0 + p1);
+				S.off[2 * lane] = (unsigned short)ex; S.off[2 * lane + 1] = (unsigned short)(ex + p0);
+				// zero the padding slots (at most 3 per list): +0.0f leaves an fp32 sum of non-negative terms unchanged
+				for (int e = c0; e < p0; ++e) S.sorted[ex + e] = 0.f;
+				for (int e = c1; e < p1; ++e) S.sorted[ex + p0 + e] = 0.f;
+			}
 			__syncthreads();
+#if OP_DESC_EXPERIMENT == 6       // timing experiment only: no scatter
+			S.sorted[lane] = val[0] + val[3];
+#else
 #pragma unroll
 			for (int c = 0; c < 8; ++c)
 				if (bin[c] >= 0) S.sorted[S.off[bin[c]] + __popcll(S.mask[bin[c]] & lt_mask)] = val[c];
+#endif
 			__syncthreads();
-			// phase 3: ordered accumulation of this lane's two bins
-			for (int e = 0; e < c0; ++e) acc0 += S.sorted[ex + e];
-			for (int e = 0; e < c1; ++e) acc1 += S.sorted[ex + c0 + e];
+			// phase 3: ordered accumulation.  Lane L owns bins L and L + 64 (cells 8 apart: when one is
+			// crowded the other is not, which evens the list lengths across the wave).  Lists are read a
+			// float4 at a time (16-byte aligned, zero-padded), the four additions of a group stay in order;
+			// the trip count is wave-uniform, lanes whose list has ended skip the group.
+			{
+				const int na = (__popcll(S.mask[lane]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64]) + 3) & ~3;
+				const f32x4* la = (const f32x4*)&S.sorted[S.off[lane]];
+				const f32x4* lb = (const f32x4*)&S.sorted[S.off[lane + 64]];
+#if OP_DESC_EXPERIMENT == 7       // timing experiment only: one accumulation round
+				const int T = 4;
+#else
+				const int T = wave_max_i(na > nb ? na : nb);
+#endif
+				for (int e = 0; e < T; e += 8) {
+					f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+					if (e < na) a0 = la[e >> 2];
+					if (e + 4 < na) a1 = la[(e >> 2) + 1];
+					if (e < nb) b0 = lb[e >> 2];
+					if (e + 4 < nb) b1 = lb[(e >> 2) + 1];
+					acc0 += a0.x; acc0 += a0.y; acc0 += a0.z; acc0 += a0.w; acc0 += a1.x; acc0 += a1.y; acc0 += a1.z; acc0 += a1.w;
+					acc1 += b0.x; acc1 += b0.y; acc1 += b0.z; acc1 += b0.w; acc1 += b1.x; acc1 += b1.y; acc1 += b1.z; acc1 += b1.w;
+				}
+			}
+			__syncthreads();
 			S.mask[2 * lane] = 0ULL; S.mask[2 * lane + 1] = 0ULL;
 			__syncthreads();
 			qhead = (qhead + n) & (QCAP - 1); qn -= n;
 		};
 
-		// phase 1a: window scan in the reference's order (xx outer, yy inner: sift.cc:110-113); the
-		// cheap tests run on all samples, survivors are queued in order and handed to the expensive
+		// phase 1a: candidates in the reference's order (xx outer, yy inner: sift.cc:110-113); the
+		// cheap tests run on all candidates, survivors are queued in order and handed to the expensive
 		// phases 64 at a time, so those always run with full wavefronts
-		int qx = lane / side, qy = lane % side;          // sample e = i0 + lane  ->  (e / side, e % side)
-		for (int i0 = 0; i0 < nsamp; i0 += 64) {
+		int qx = lane / side, qy = lane % side;          // full-window walk: sample e = i0 + lane  ->  (e / side, e % side)
+		for (int i0 = 0; i0 < ncand; i0 += 64) {
 			bool ok = false;
 			float x_rot = 0.f, y_rot = 0.f;
 			int gi = 0;
-			if (i0 + lane < nsamp) {
-				const int xx = qx - radius, yy = qy - radius;
+			if (i0 + lane < ncand) {
+				int xx, yy;
+				if (cols) {
+					const int e = i0 + lane, c = S.colmap[e];
+					xx = c - radius; yy = (int)S.col_lo[c] + (e - (int)S.col_start[c]);
+				} else { xx = qx - radius; yy = qy - radius; }
 				const int nowx = kp.x + xx, nowy = kp.y + yy;
 				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
 					const float fxx = (float)xx, fyy = (float)yy;
 					if (!(fxx * fxx + fyy * fyy > fr2)) {
-						y_rot = ((float)(-xx) * sinort + fyy * cosort) / hist_w;
-						x_rot = (fxx * cosort + fyy * sinort) / hist_w;
+						y_rot = (float)((double)((float)(-xx) * sinort + fyy * cosort) * rd);
+						x_rot = (float)((double)(fxx * cosort + fyy * sinort) * rd);
 						const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
 						// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
 						ok = (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f);
@@ -155,21 +293,25 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 					}
 				}
 			}
-			qy += 64;
-			while (qy >= side) { qy -= side; ++qx; }
+			if (!cols) { qy += 64; while (qy >= side) { qy -= side; ++qx; } }
 			const unsigned long long mask = __ballot(ok);
 			if (ok) {
 				const int qi = (qhead + qn + __popcll(mask & lt_mask)) & (QCAP - 1);
 				S.q_gi[qi] = gi; S.q_xr[qi] = x_rot; S.q_yr[qi] = y_rot;
 			}
 			qn += __popcll(mask);
+#if OP_DESC_EXPERIMENT == 3       // timing experiment only: scan without the batches
+			if (qn >= 64) { qhead = (qhead + 64) & (QCAP - 1); qn -= 64; acc0 += x_rot; }
+		}
+#else
 			if (qn >= 64) { __syncthreads(); process_batch(64); }
 		}
 		if (qn > 0) { __syncthreads(); process_batch(qn); }
+#endif
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
-		S.hist[2 * lane] = acc0;
-		S.hist[2 * lane + 1] = acc1;
+		S.hist[lane] = acc0;
+		S.hist[lane + 64] = acc1;
 		__syncthreads();
 		float sum = 0.f;
 		for (int i = 0; i < 128; ++i) sum += S.hist[i];

@@ -236,11 +236,33 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 // Samples are evaluated 64 at a time, but each histogram bin is accumulated by ONE lane walking
 // the samples in the reference's (xx outer, yy inner) order, so the fp32 sums round identically.
 constexpr int ORI_BINS = 36;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// wave64 inclusive add-scan / max on the VALU data-parallel primitives (see descriptor.hip)
+__device__ __forceinline__ int ori_scan_add(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+	return v;
+}
+__device__ __forceinline__ int ori_max(int v) {
+	int t;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+	t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+	return __builtin_amdgcn_readlane(v, 63);
+}
 
 __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* refined, const int* refined_count,
 		int cap, float* dirs, int* ndirs) {
 	__shared__ unsigned long long s_mask[ORI_BINS];   // per bin: bit l = lane l's sample of this round falls into it
-	__shared__ float s_sorted[64];                     // the round's values, bin-major, sample order inside a bin
+	__shared__ __attribute__((aligned(16))) float s_sorted[64 + 3 * ORI_BINS + 12];   // the round's values, bin-major, sample order inside a bin; lists 16-byte aligned, zero-padded to float4s
 	__shared__ unsigned short s_off[64];
 	__shared__ float s_hist[ORI_BINS];
 	const int img = blockIdx.y;
@@ -293,16 +315,23 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 			if (bin >= 0) atomicOr(&s_mask[bin], 1ULL << lane);
 			__syncthreads();
 			const unsigned long long m = lane < ORI_BINS ? s_mask[lane] : 0ULL;
-			const int c = __popcll(m);
-			int incl = c;                                 // inclusive wave scan of the bin counts
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-			const int ex = incl - c;
+			const int c = __popcll(m), pc = (c + 3) & ~3;   // list length, rounded up to whole float4s
+			const int ex = ori_scan_add(pc) - pc;            // exclusive wave scan of the padded bin sizes
 			s_off[lane] = (unsigned short)ex;
+			for (int e = c; e < pc; ++e) s_sorted[ex + e] = 0.f;       // +0.0f padding leaves the non-negative fp32 sums unchanged
 			__syncthreads();
 			if (bin >= 0) s_sorted[s_off[bin] + __popcll(s_mask[bin] & lt_mask)] = val;
 			__syncthreads();
-			for (int e = 0; e < c; ++e) h += s_sorted[ex + e];
+			{
+				const f32x4* l = (const f32x4*)&s_sorted[ex];
+				const int T = ori_max(pc);
+				for (int e = 0; e < T; e += 8) {
+					f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+					if (e < pc) a0 = l[e >> 2];
+					if (e + 4 < pc) a1 = l[(e >> 2) + 1];
+					h += a0.x; h += a0.y; h += a0.z; h += a0.w; h += a1.x; h += a1.y; h += a1.z; h += a1.w;
+				}
+			}
 			if (lane < ORI_BINS) s_mask[lane] = 0ULL;
 			__syncthreads();
 		}

@@ -17,6 +17,7 @@ VARIANTS = {
     "window10_wide": dict(GAUSS_WINDOW_FACTOR=10, NUM_SCALE=9, SCALE_FACTOR=1.3),
     "tiny_working_size": dict(SIFT_WORKING_SIZE=130, CONTRAST_THRES=1e-2, PRE_COLOR_THRES=2e-2),   # 149 x 111 working image, octaves down to 53 x 40: bands and segments smaller than a workgroup
     "large_working_size": dict(SIFT_WORKING_SIZE=1500, NUM_OCTAVE=5),
+    "wide_descriptor_window": dict(DESC_HIST_SCALE_FACTOR=6),       # descriptor radius ~37: windows wider than 64 columns
     "thresholds": dict(CONTRAST_THRES=2e-2, PRE_COLOR_THRES=3e-2, EDGE_RATIO=10, JUDGE_EXTREMA_DIFF_THRES=1e-3,
                        ORI_RADIUS=3.5, ORI_HIST_SMOOTH_COUNT=1, DESC_HIST_SCALE_FACTOR=2, CALC_OFFSET_DEPTH=3),
 }
