@@ -14,6 +14,9 @@
 // reverse sweep over the survivors only, whose epilogue applies the second test.  MFMA results
 // only RANK candidates; the reference's float arithmetic decides every match.
 #include "internal.hpp"
+#ifndef OP_MATCH_EXPERIMENT
+#define OP_MATCH_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
+#endif
 #include <cfloat>
 #include <cstring>
 #include <memory>
@@ -264,6 +267,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		f32x4 nyh[4];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) nyh[g] = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
+#if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
+		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
+#else
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
 			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
@@ -272,12 +278,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
+#endif
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 			const float sc = acc[reg] - nyh[reg >> 2][reg & 3];
+#if OP_MATCH_EXPERIMENT == 1      // timing experiment: running maximum only, no top-4 network
+			if (sc > ts[0]) { ts[0] = sc; ti[0] = t * 32 + i; }
+#else
 			topk_insert(ts, ti, sc, t * 32 + i);
+#endif
 		}
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		__syncthreads();
