@@ -46,6 +46,13 @@ op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::ve
 	return m;
 }
 
+#if OP_MATCH_EXPERIMENT == 9
+__device__ unsigned long long g_match_timers[8];
+#define STAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -228,38 +235,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
 	// global -> registers and registers -> LDS are split so that the next tile's loads are in flight
 	// while the MFMAs of the current tile run; the LDS store happens after them
-	uint4 stage[4]; float stage_ny = 0.f;
+	// Four 16-byte blocks per thread and tile, in four named registers (an array here ended up in scratch
+	// memory once the loads lost their predication).  No exec-mask branches: rows past the end of Y
+	// re-read its last row, their columns cannot rank because their |y|^2/2 is FLT_MAX.
+	uint4 st0, st1, st2, st3; float stage_ny = 0.f;
+	const int f_yr = tid >> 5, f_c4 = tid & 31;          // block e = tid + 256 r  ->  row f_yr + 8 r, column block f_c4
 	auto fetch_tile = [&](int t) {
-		// 32 split rows x 512 B = 1024 x 16 B, 4 per thread
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int e = tid + 256 * r;          // 16-byte index
-			const int yr = e >> 5, c4 = e & 31;
-			const int gy = t * 32 + yr;
-			uint4 v = {0u, 0u, 0u, 0u};
-			if (gy < ky) v = YS[(long long)gy * 32 + c4];
-			stage[r] = v;
-		}
-		if (tid < 32) {
-			const int gy = t * 32 + tid;
-			stage_ny = gy < ky ? 0.5f * ny[gy] : FLT_MAX;   // padded columns can never rank
-		}
+		const int r0 = t * 32 + f_yr, last = ky - 1;
+		const int g0 = r0 < last ? r0 : last, g1 = r0 + 8 < last ? r0 + 8 : last, g2 = r0 + 16 < last ? r0 + 16 : last, g3 = r0 + 24 < last ? r0 + 24 : last;
+		st0 = YS[(long long)g0 * 32 + f_c4];
+		st1 = YS[(long long)g1 * 32 + f_c4];
+		st2 = YS[(long long)g2 * 32 + f_c4];
+		st3 = YS[(long long)g3 * 32 + f_c4];
+		const int gy = t * 32 + (tid & 31);
+		const float v = 0.5f * ny[gy < ky ? gy : last];
+		stage_ny = gy < ky ? v : FLT_MAX;   // padded columns can never rank
 	};
 	auto commit_tile = [&](int buf) {
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int e = tid + 256 * r;
-			*(uint4*)(&s_y[buf][(e >> 5) * YP + (e & 31) * 4]) = stage[r];
-		}
+		float* d = &s_y[buf][f_yr * YP + f_c4 * 4];
+		*(uint4*)(d) = st0;
+		*(uint4*)(d + 8 * YP) = st1;
+		*(uint4*)(d + 16 * YP) = st2;
+		*(uint4*)(d + 24 * YP) = st3;
 		if (tid < 32) s_nyh[buf][tid] = stage_ny;
 	};
 
 	fetch_tile(0);
 	commit_tile(0);
 	__syncthreads();
+#if OP_MATCH_EXPERIMENT == 9
+	unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
 	for (int t = 0; t < ntiles; ++t) {
 		const int buf = t & 1;
 		if (t + 1 < ntiles) fetch_tile(t + 1);
+		STAMP(0);
 		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
 		// |y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h, fetched ahead of the MFMA
@@ -267,9 +277,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		f32x4 nyh[4];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) nyh[g] = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
-#if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
-		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
-#else
 #if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
 		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
 #else
@@ -282,21 +289,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
 #endif
+#if OP_MATCH_EXPERIMENT == 9
+		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
 #endif
+		STAMP(1);
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
+		// (screening the 16 scores with wave ballots first and branching on the scalar masks was measured:
+		// no gain over the per-score compare + branch below)
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
 			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 			const float sc = acc[reg] - nyh[reg >> 2][reg & 3];
 #if OP_MATCH_EXPERIMENT == 1      // timing experiment: running maximum only, no top-4 network
 			if (sc > ts[0]) { ts[0] = sc; ti[0] = t * 32 + i; }
+#elif OP_MATCH_EXPERIMENT == 3    // timing experiment: scores are only folded into one value
+			ts[0] = fmaxf(ts[0], sc);
 #else
 			topk_insert(ts, ti, sc, t * 32 + i);
 #endif
 		}
+		STAMP(2);
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
+		STAMP(3);
 		__syncthreads();
+		STAMP(4);
 	}
+#if OP_MATCH_EXPERIMENT == 9
+	if (tid == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&g_match_timers[k], tacc[k]); atomicAdd(&g_match_timers[5], (unsigned long long)ntiles); tlast = clock64(); }
+#endif
 	// merge the two lane halves of each X row; both halves then read the merged top-4
 #pragma unroll
 	for (int r = 0; r < NK; ++r) { s_ms[wave][j][h][r] = ts[r]; s_mi[wave][j][h][r] = ti[r]; }
@@ -385,6 +405,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		} else if (REV) finish_reverse(S, pd, wk.pair, a_row, next_min);
 		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
 	}
+#if OP_MATCH_EXPERIMENT == 9
+	if (tid == 0) { atomicAdd(&g_match_timers[6], clock64() - tlast); atomicAdd(&g_match_timers[7], 1ULL); }
+#endif
 }
 
 // rows whose NK ranked candidates all fell inside the error margin (near-duplicate descriptors):
@@ -601,6 +624,15 @@ done:
 	*out = m;
 	return OP_OK;
 }
+
+#if OP_MATCH_EXPERIMENT == 9
+// timing experiment only: cycles of wave 0 per phase, summed over all workgroups since the last read
+int op_debug_match_timers(unsigned long long* out) {
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_timers), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+	unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_match_timers), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out) {
 	if (!idx_pairs || !counts || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_matches_from_host: bad argument");
