@@ -532,7 +532,7 @@ def main():
     # ---------------- strong-scaled jobs in the same line: config 4 (N>1, weak headline) and config 5 ----------------
     if not args.no_match:
         from bench_match import run_strong_job
-        if world > 1 and args.scaling == "weak" and not args.no_strong:
+        if (world > 1 or dist is not None) and args.scaling == "weak" and not args.no_strong:      # also under OPENPANO_FORCE_DIST: the path must have run on hardware
             out["strong_config4"] = run_strong_job(hip, ctx, cfg, "config4", args, dist, dev, rank, world, barrier, log)
         if not args.no_config5:
             out["config5"] = run_strong_job(hip, ctx, cfg, "config5", args, dist, dev, rank, world, barrier, log)

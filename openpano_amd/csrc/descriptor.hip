@@ -154,15 +154,19 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		auto process_batch = [&](int n) {
 			const bool ok = lane < n;
 			const int qi = (qhead + lane) & (QCAP - 1);
-			int bin[8]; float val[8];
+			int cb[4]; float vA[4], vB[4]; int hq = 0;       // per touched cell: first bin of the cell, values for bins h0 and h0 + 1
 #pragma unroll
-			for (int c = 0; c < 8; ++c) { bin[c] = -1; val[c] = 0.f; }
+			for (int u = 0; u < 4; ++u) { cb[u] = -1; vA[u] = 0.f; vB[u] = 0.f; }
 			if (ok) {
 				const int gi = S.q_gi[qi];
 				const float x_rot = S.q_xr[qi], y_rot = S.q_yr[qi];
 				const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
+#if OP_DESC_EXPERIMENT == 4
+				const float gdy = 0.f, gdx = 0.f; (void)gi;
+#else
 				const float gdy = g_img[gi + w] - g_img[gi - w];
 				const float gdx = g_img[gi + 1] - g_img[gi - 1];
+#endif
 #if OP_DESC_EXPERIMENT == 1       // timing experiment only: no transcendental twins
 				const float now_mag = gdx + gdy;
 				float now_ort = fabsf(gdy - gdx) + 3.f;
@@ -186,6 +190,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				const int yb = (int)yf, xb = (int)xf, h0 = (int)hf;
 				const float ybind = ybin - yf, xbind = xbin - xf, hbind = hbin - hf;
 				const float omh = 1 - hbind;
+				hq = h0 & 7;                                           // hbinf % 8; the second bin is (hbinf + 1) % 8
 #pragma unroll
 				for (int dy = 0; dy < 2; ++dy) {
 					const float w_y = weight * (dy ? ybind : 1 - ybind);
@@ -194,32 +199,29 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 						const int cy = yb + dy, cx = xb + dx;
 						if ((unsigned)cy < 4u && (unsigned)cx < 4u) {        // between(., 0, DESC_HIST_WIDTH)
 							const float w_x = w_y * (dx ? xbind : 1 - xbind);
-							const int cellbase = (cy * 4 + cx) * 8, u = dy * 2 + dx;
-							bin[2 * u] = cellbase + (h0 & 7);          val[2 * u] = w_x * omh;       // hbinf % 8
-							bin[2 * u + 1] = cellbase + ((h0 + 1) & 7);  val[2 * u + 1] = w_x * hbind;  // (hbinf + 1) % 8
+							const int u = dy * 2 + dx;
+							cb[u] = (cy * 4 + cx) * 8; vA[u] = w_x * omh; vB[u] = w_x * hbind;
 						}
 					}
 				}
 			}
+			// phase 2: stable counting sort of the contributions by bin.  A sample touches, per cell, the two
+			// adjacent orientation bins h0 and h0 + 1: ONE mask bit per (cell, h0) records both (4 LDS atomics
+			// per sample instead of 8), the contributors of bin (cell, k) are mask[cell][k] (their first value)
+			// and mask[cell][k - 1] (their second) -- disjoint sets, merged in lane = sample order.
 #if OP_DESC_EXPERIMENT == 2       // timing experiment only: no ordering machinery
-			for (int c = 0; c < 8; ++c) { acc0 += val[c]; acc1 += (float)bin[c]; }
+			for (int u = 0; u < 4; ++u) { acc0 += vA[u] + vB[u]; acc1 += (float)cb[u]; }
 			qhead = (qhead + n) & (QCAP - 1); qn -= n;
 			return;
 #endif
-			// phase 2: stable counting sort of the contributions by bin
-#if OP_DESC_EXPERIMENT == 5       // timing experiment only: plain stores instead of LDS atomics
 #pragma unroll
-			for (int c = 0; c < 8; ++c)
-				if (bin[c] >= 0) S.mask[bin[c]] = 1ULL << lane;
-#else
-#pragma unroll
-			for (int c = 0; c < 8; ++c)
-				if (bin[c] >= 0) atomicOr(&S.mask[bin[c]], 1ULL << lane);
-#endif
+			for (int u = 0; u < 4; ++u)
+				if (cb[u] >= 0) atomicOr(&S.mask[cb[u] + hq], 1ULL << lane);
 			__syncthreads();
 			{
-				const unsigned long long m0 = S.mask[2 * lane], m1 = S.mask[2 * lane + 1];
-				const int c0 = __popcll(m0), c1 = __popcll(m1);
+				const int base = (lane >> 2) * 8, k0 = 2 * (lane & 3);          // this lane computes the offsets of bins 2 lane, 2 lane + 1
+				const unsigned long long mp = S.mask[base + ((k0 + 7) & 7)], m0 = S.mask[base + k0], m1 = S.mask[base + k0 + 1];
+				const int c0 = __popcll(m0 | mp), c1 = __popcll(m1 | m0);
 				const int p0 = (c0 + 3) & ~3, p1 = (c1 + 3) & ~3;         // list lengths rounded up to whole float4s
 				const int incl = wave_scan_add(p0 + p1);                   // inclusive wave scan of the per-lane pair sizes
 				const int ex = incl - (p0 + p1);
@@ -229,20 +231,22 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				for (int e = c1; e < p1; ++e) S.sorted[ex + p0 + e] = 0.f;
 			}
 			__syncthreads();
-#if OP_DESC_EXPERIMENT == 6       // timing experiment only: no scatter
-			S.sorted[lane] = val[0] + val[3];
-#else
 #pragma unroll
-			for (int c = 0; c < 8; ++c)
-				if (bin[c] >= 0) S.sorted[S.off[bin[c]] + __popcll(S.mask[bin[c]] & lt_mask)] = val[c];
-#endif
+			for (int u = 0; u < 4; ++u)
+				if (cb[u] >= 0) {
+					const int hn = (hq + 1) & 7;
+					const unsigned long long mp = S.mask[cb[u] + ((hq + 7) & 7)], m0 = S.mask[cb[u] + hq], mn = S.mask[cb[u] + hn];
+					S.sorted[S.off[cb[u] + hq] + __popcll((m0 | mp) & lt_mask)] = vA[u];
+					S.sorted[S.off[cb[u] + hn] + __popcll((mn | m0) & lt_mask)] = vB[u];
+				}
 			__syncthreads();
 			// phase 3: ordered accumulation.  Lane L owns bins L and L + 64 (cells 8 apart: when one is
 			// crowded the other is not, which evens the list lengths across the wave).  Lists are read a
 			// float4 at a time (16-byte aligned, zero-padded), the four additions of a group stay in order;
 			// the trip count is wave-uniform, lanes whose list has ended skip the group.
 			{
-				const int na = (__popcll(S.mask[lane]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64]) + 3) & ~3;
+				const int bprev = (lane & ~7) | ((lane + 7) & 7);          // bin (cell, k - 1) of bin `lane` = (cell, k)
+				const int na = (__popcll(S.mask[lane] | S.mask[bprev]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64] | S.mask[bprev + 64]) + 3) & ~3;
 				const f32x4* la = (const f32x4*)&S.sorted[S.off[lane]];
 				const f32x4* lb = (const f32x4*)&S.sorted[S.off[lane + 64]];
 #if OP_DESC_EXPERIMENT == 7       // timing experiment only: one accumulation round
