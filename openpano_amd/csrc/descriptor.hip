@@ -31,13 +31,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int QCAP = 128;            // survivor queue (power of two, >= 2 x 64)
-constexpr int COLCAP = 2048;         // candidate samples of one keypoint in the column-interval enumeration
+constexpr int COLCAP = 1024;         // candidate samples of one keypoint in the column-interval enumeration (the shipped config needs < 800)
 
 struct DescLds {
 	unsigned long long mask[128];    // per bin: bit l = lane l's sample of the current batch contributes
 	float sorted[512 + 3 * 128 + 64] __attribute__((aligned(16)));   // the batch's contributions, bin-major, sample order inside a bin; every list starts on a 16-byte boundary and is zero-padded to a multiple of 4
 	unsigned short off[128];         // first slot of every bin in sorted[]
-	float hist[128];
 	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates
 	float q_xr[QCAP], q_yr[QCAP];
 	uint64_t exptab[32];             // glibc's exp2f table (devmath.hpp), staged once per workgroup
@@ -314,16 +313,18 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 #endif
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
-		S.hist[lane] = acc0;
-		S.hist[lane + 64] = acc1;
+		// (the histogram reuses the list buffer: 8 KB of LDS per workgroup = 20 workgroups, 5 waves per SIMD)
+		float* hist = S.sorted;
+		hist[lane] = acc0;
+		hist[lane + 64] = acc1;
 		__syncthreads();
 		float sum = 0.f;
-		for (int i = 0; i < 128; ++i) sum += S.hist[i];
+		for (int i = 0; i < 128; ++i) sum += hist[i];
 		float* out = desc + kk * 128;
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {
 			const int i = lane + 64 * t;
-			const float v = S.hist[i] / sum;
+			const float v = hist[i] / sum;
 			out[i] = sqrtf(v) * (float)p.desc_int_factor;
 		}
 		if (lane == 0) {   // feature/feature.cc:23-26
