@@ -231,13 +231,22 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	if (host_bytes) HIPCHK(W.staging.ensure(host_bytes));
 	{
 		const void** hs = (const void**)W.pinned;
-		size_t so = 0;
-		for (int i = 0; i < n; ++i) {
-			if (imgs[i]->on_device) hs[i] = imgs[i]->data;
-			else {
-				void* d = (char*)W.staging.p + so;
-				HIPCHK(hipMemcpyAsync(d, imgs[i]->data, img_bytes, hipMemcpyHostToDevice, st));
-				hs[i] = d; so += img_stride;
+		// host images that lie back to back at the staging stride (a decoder's output pool, one pinned block
+		// sliced into frames) travel in ONE copy: 38 separate 3 MB copies reach about half the link rate
+		bool packed = host_bytes == img_stride * (size_t)n && n > 1;
+		for (int i = 1; i < n && packed; ++i) packed = (const char*)imgs[i]->data == (const char*)imgs[0]->data + (size_t)i * img_stride;
+		if (packed) {
+			HIPCHK(hipMemcpyAsync(W.staging.p, imgs[0]->data, img_stride * (size_t)(n - 1) + img_bytes, hipMemcpyHostToDevice, st));
+			for (int i = 0; i < n; ++i) hs[i] = (char*)W.staging.p + (size_t)i * img_stride;
+		} else {
+			size_t so = 0;
+			for (int i = 0; i < n; ++i) {
+				if (imgs[i]->on_device) hs[i] = imgs[i]->data;
+				else {
+					void* d = (char*)W.staging.p + so;
+					HIPCHK(hipMemcpyAsync(d, imgs[i]->data, img_bytes, hipMemcpyHostToDevice, st));
+					hs[i] = d; so += img_stride;
+				}
 			}
 		}
 		HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
