@@ -47,7 +47,13 @@ op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::ve
 }
 
 #if OP_MATCH_EXPERIMENT == 9
-__device__ unsigned long long g_match_timers[8];
+__device__ unsigned long long g_match_timers[10];   // 0-4 phases, 5 tiles, 6 epilogue cycles, 7 workgroups, 8 / 9 workgroup lifetime in 100 MHz ticks / shader cycles
+__device__ int g_occ[2048];                         // workgroups resident per CU right now (key: XCC, SE, SH, CU of HW_ID)
+__device__ unsigned long long g_occ_hist[8];         // how many workgroups found c = 1..7 residents (themselves included) on their CU at start
+__device__ __forceinline__ int occ_key() {
+	const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_HW_ID, HW_REG_XCC_ID
+	return (int)(((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
+}
 #define STAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -68,7 +74,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // so the dense contraction runs once per unordered pair plus a small reverse strip, i.e. the
 // algorithmic 2*128*K_i*K_j flop of SURVEY 8(d) instead of twice that.
 struct WorkItem { int pair, rowblock; };
-struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; };
+struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; int ia, ib; };   // ia / ib: image indices of the A / B set (the exact-scan queue is grouped by the image it scans)
 
 constexpr int YP = 132;   // LDS pitch of a Y tile row (floats): 16-B slot rotation -> conflict-free b128
 
@@ -133,6 +139,38 @@ __device__ __forceinline__ void topk_insert(float (&ts)[NK], int (&ti)[NK], floa
 	}
 }
 
+// The sweep's running top-NK is kept on KEYS: the score with its low 4 mantissa bits replaced by the MFMA
+// register slot (0..15) it came from.  A key is still an ordinary float within 16 ulp of the score
+// (|key - score| < 2^-19 |score| <= 2^-20 (|x|^2 + max|y|^2), paid for in the margin E below), so the four
+// kept keys are updated by one v_max and three v_med3 per score -- no compares, no selects, no branches --
+// and the slot is recovered from the key's bits.  Which TILE a kept key came from is settled once per tile
+// (topk_attribute): the new list is a merge of the old list (relative order kept) and this tile's keys, so
+// walking the new list against the next unused old entry tells old (keeps its tile) from new (this tile);
+// when a new key equals the old entry it is compared with, the old one is taken first -- equal keys are
+// interchangeable, the other one is met at the next slot.
+__device__ __forceinline__ float score_key(float s, int slot) { return __uint_as_float((__float_as_uint(s) & ~15u) | (unsigned)slot); }
+__device__ __forceinline__ void topk_keys(float (&k)[NK], float key) {
+	const float n3 = __builtin_amdgcn_fmed3f(k[2], k[3], key), n2 = __builtin_amdgcn_fmed3f(k[1], k[2], key), n1 = __builtin_amdgcn_fmed3f(k[0], k[1], key);
+	float m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(k[0]), "v"(key));        // fmaxf() would canonicalise both operands first (two more VALU operations)
+	k[0] = m;
+	k[1] = n1; k[2] = n2; k[3] = n3;
+}
+__device__ __forceinline__ void topk_attribute(const float (&o)[NK], const float (&k)[NK], int (&tt)[NK], int t) {
+	const int T0 = tt[0], T1 = tt[1], T2 = tt[2], T3 = tt[3];
+	const bool e0 = k[0] == o[0];
+	tt[0] = e0 ? T0 : t;
+	const float v1 = e0 ? o[1] : o[0]; const int w1 = e0 ? T1 : T0;                 // next unused old entry
+	const bool e1 = k[1] == v1;
+	tt[1] = e1 ? w1 : t;
+	const float v2 = e1 ? (e0 ? o[2] : o[1]) : v1; const int w2 = e1 ? (e0 ? T2 : T1) : w1;
+	const bool e2 = k[2] == v2;
+	tt[2] = e2 ? w2 : t;
+	const bool b2 = e0 && e1, b1 = e0 || e1;                                       // old entries used by slots 0, 1: 2 / >= 1
+	const float nx = b2 ? o[3] : (b1 ? o[2] : o[1]); const int nw = b2 ? T3 : (b1 ? T2 : T1);   // the old entry after v2
+	const float v3 = e2 ? nx : v2; const int w3 = e2 ? nw : w2;
+	tt[3] = (k[3] == v3) ? w3 : t;
+}
+
 // feature/dist.cc:22-57 without the early-out (which never changes a result: partial sums are
 // monotone, so a distance it cuts off could not have lowered the running minima)
 __device__ __forceinline__ float euclidean_sqr_exact(const float* __restrict__ x, const float* __restrict__ y) {
@@ -161,6 +199,7 @@ struct MatchState {
 	int* nsurv;         // per pair
 	int* mlist;         // accepted matches: [0] = count, then (pair, a, b) triples in arrival order
 	int* slow_fwd; int* slow_rev;   // rows needing a full scan: (pair, row) pairs ...
+	int* slow_sorted;   // ... and the queue being scanned, grouped by scanned image (k_slow_order)
 	int* slow_fwd_n; int* slow_rev_n;   // ... and their counts
 	int slow_cap;
 	float rr;           // MATCH_REJECT_NEXT_RATIO^2 (matcher.cc:16)
@@ -228,6 +267,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	uint4 xh[8], xl[8];   // MFMA B operands: block kb covers k = 16 kb + 8 h .. + 7 of row j
 #pragma unroll
 	for (int kb = 0; kb < 8; ++kb) { xh[kb] = XS[2 * kb + h]; xl[kb] = XS[16 + 2 * kb + h]; }
+	// The X fragments must have LANDED before the tile loop: a load still pending at the loop header makes
+	// the compiler's wait-count pass put `s_waitcnt vmcnt(0/1)` in front of the MFMAs that read it in EVERY
+	// iteration, and since the counter is in order that drains the next tile's prefetch in the middle of
+	// the MFMA chain.  Using the registers here forces the wait once, outside the loop.
+#pragma unroll
+	for (int kb = 0; kb < 8; ++kb) asm volatile("" :: "v"(xh[kb].x), "v"(xl[kb].x));
 	float ts[NK]; int ti[NK];
 #pragma unroll
 	for (int r = 0; r < NK; ++r) { ts[r] = -FLT_MAX; ti[r] = -1; }
@@ -238,7 +283,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	// Four 16-byte blocks per thread and tile, in four named registers (an array here ended up in scratch
 	// memory once the loads lost their predication).  No exec-mask branches: rows past the end of Y
 	// re-read its last row, their columns cannot rank because their |y|^2/2 is FLT_MAX.
-	uint4 st0, st1, st2, st3; float stage_ny = 0.f;
+	uint4 st0, st1, st2, st3; float stage_ny = 0.f; bool stage_pad = false;
 	const int f_yr = tid >> 5, f_c4 = tid & 31;          // block e = tid + 256 r  ->  row f_yr + 8 r, column block f_c4
 	auto fetch_tile = [&](int t) {
 		const int r0 = t * 32 + f_yr, last = ky - 1;
@@ -247,9 +292,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		st1 = YS[(long long)g1 * 32 + f_c4];
 		st2 = YS[(long long)g2 * 32 + f_c4];
 		st3 = YS[(long long)g3 * 32 + f_c4];
+		// the raw |y|^2 only: any arithmetic on it here would wait for the load at the top of the iteration
 		const int gy = t * 32 + (tid & 31);
-		const float v = 0.5f * ny[gy < ky ? gy : last];
-		stage_ny = gy < ky ? v : FLT_MAX;   // padded columns can never rank
+		stage_ny = ny[gy < ky ? gy : last];
+		stage_pad = gy >= ky;
 	};
 	auto commit_tile = [&](int buf) {
 		float* d = &s_y[buf][f_yr * YP + f_c4 * 4];
@@ -257,7 +303,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		*(uint4*)(d + 8 * YP) = st1;
 		*(uint4*)(d + 16 * YP) = st2;
 		*(uint4*)(d + 24 * YP) = st3;
-		if (tid < 32) s_nyh[buf][tid] = stage_ny;
+		if (tid < 32) s_nyh[buf][tid] = stage_pad ? FLT_MAX : 0.5f * stage_ny;   // padded columns can never rank
 	};
 
 	fetch_tile(0);
@@ -265,6 +311,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	__syncthreads();
 #if OP_MATCH_EXPERIMENT == 9
 	unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+	const unsigned long long wall0 = wall_clock64(), cyc0 = tlast;
+	const int okey = occ_key();
+	if (tid == 0) { const int c = atomicAdd(&g_occ[okey], 1) + 1; atomicAdd(&g_occ_hist[c < 7 ? c : 7], 1ULL); }
 #endif
 	for (int t = 0; t < ntiles; ++t) {
 		const int buf = t & 1;
@@ -280,6 +329,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 #if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
 		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
 #else
+#if OP_MATCH_EXPERIMENT == 11 || OP_MATCH_EXPERIMENT == 13
+		__builtin_amdgcn_s_setprio(3);
+#endif
+#if OP_MATCH_EXPERIMENT == 12 || OP_MATCH_EXPERIMENT == 13
+		f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (int kb = 0; kb < 8; ++kb) {
+			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
+			const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[kb]), bl = __builtin_bit_cast(bf16x8, xl[kb]);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+			acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+			if (kb & 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+			else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+		}
+#pragma unroll
+		for (int reg = 0; reg < 16; ++reg) acc[reg] += acc2[reg];
+#else
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
 			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
@@ -289,6 +355,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
 #endif
+#if OP_MATCH_EXPERIMENT == 11 || OP_MATCH_EXPERIMENT == 13
+		__builtin_amdgcn_s_setprio(0);
+#endif
+#endif
 #if OP_MATCH_EXPERIMENT == 9
 		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
 #endif
@@ -296,18 +366,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
 		// (screening the 16 scores with wave ballots first and branching on the scalar masks was measured:
 		// no gain over the per-score compare + branch below)
+#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
+		const float old_keys[NK] = {ts[0], ts[1], ts[2], ts[3]};
+#endif
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
-			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h; (void)i;
 			const float sc = acc[reg] - nyh[reg >> 2][reg & 3];
 #if OP_MATCH_EXPERIMENT == 1      // timing experiment: running maximum only, no top-4 network
 			if (sc > ts[0]) { ts[0] = sc; ti[0] = t * 32 + i; }
 #elif OP_MATCH_EXPERIMENT == 3    // timing experiment: scores are only folded into one value
 			ts[0] = fmaxf(ts[0], sc);
+#elif OP_MATCH_EXPERIMENT == 14   // timing experiment: branch-free top-4 VALUES (max + 3 med3 on keys carrying the register slot), no indices
+			{
+				const float key = __uint_as_float((__float_as_uint(sc) & ~15u) | (unsigned)reg);
+				const float n3 = __builtin_amdgcn_fmed3f(ts[2], ts[3], key), n2 = __builtin_amdgcn_fmed3f(ts[1], ts[2], key), n1 = __builtin_amdgcn_fmed3f(ts[0], ts[1], key);
+				ts[0] = __builtin_amdgcn_fmed3f(ts[0], key, __builtin_inff()); ts[1] = n1; ts[2] = n2; ts[3] = n3;
+			}
 #else
-			topk_insert(ts, ti, sc, t * 32 + i);
+			topk_keys(ts, score_key(sc, reg));
 #endif
 		}
+#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
+		topk_attribute(old_keys, ts, ti, t);          // ti[] holds TILE numbers until the sweep ends
+#endif
 		STAMP(2);
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		STAMP(3);
@@ -317,35 +399,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 #if OP_MATCH_EXPERIMENT == 9
 	if (tid == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&g_match_timers[k], tacc[k]); atomicAdd(&g_match_timers[5], (unsigned long long)ntiles); tlast = clock64(); }
 #endif
-	// merge the two lane halves of each X row; both halves then read the merged top-4
+	// (tile, slot) -> column: slot reg of lane half h is column (reg & 3) + 8 (reg >> 2) + 4 h of its tile; never-filled
+	// entries (tile -1) and the padded columns of the last tile (score -FLT_MAX, they rank above nothing real) are no candidates
+#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
+#pragma unroll
+	for (int r = 0; r < NK; ++r) {
+		const int reg = (int)(__float_as_uint(ts[r]) & 15u);
+		const int col = ti[r] * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+		ti[r] = (ti[r] < 0 || col >= ky) ? -1 : col;
+	}
+#endif
+	// the two lane halves of an X row exchange their lists; both then derive the same candidate set
 #pragma unroll
 	for (int r = 0; r < NK; ++r) { s_ms[wave][j][h][r] = ts[r]; s_mi[wave][j][h][r] = ti[r]; }
 	__syncthreads();
-	if (h == 0) {
-#pragma unroll
-		for (int r = 0; r < NK; ++r) topk_insert(ts, ti, s_ms[wave][j][1][r], s_mi[wave][j][1][r]);
-#pragma unroll
-		for (int r = 0; r < NK; ++r) { s_ms[wave][j][0][r] = ts[r]; s_mi[wave][j][0][r] = ti[r]; }
-	}
-	__syncthreads();
 
-	// ---- candidate set (identical in both halves): merged top-NK entries within E of the 2nd best ----
+	// ---- candidate set (identical in both halves): every kept entry within E of the row's 2nd best.  The lists
+	// are NOT merged down to four: a half's list holds every column of that half above its 4th key, so as long as
+	// each half's 4th key is below the threshold the union of the two lists is complete -- up to 3 + 3 candidates.
+	// Only a half whose four entries ALL sit inside the margin sends the row to the exact full scan (four
+	// near-ties in one half: an order of magnitude rarer than four in the row).
 	const float gmax = __uint_as_float(*S.gmax_bits);
-	const float E = 8e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
-	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];
-	const float thr = ms[1] - E;
-	const bool overflow = mi[NK - 1] >= 0 && ms[NK - 1] >= thr;     // even the NK-th entry is inside the margin
-	int c[NK]; int nc = 0;
+	const float E = 8.2e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);   // 8e-5 for the MFMA scores + 2 * 2^-20 for the keys' slot bits
+	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];            // [half][NK] contiguous
+	const float second = fmaxf(fminf(ms[0], ms[NK]), fmaxf(ms[1], ms[NK + 1]));      // 2nd largest key of the row (invalid entries rank below every real one)
+	const float thr = second - E;
+	const bool overflow = (mi[NK - 1] >= 0 && ms[NK - 1] >= thr) || (mi[2 * NK - 1] >= 0 && ms[2 * NK - 1] >= thr);
+	constexpr int NC = 2 * (NK - 1);
+	int c[NC]; int nc = 0;
 #pragma unroll
-	for (int r = 0; r < NK; ++r) c[r] = 0x7fffffff;
+	for (int r = 0; r < NC; ++r) c[r] = 0x7fffffff;
 #pragma unroll
-	for (int r = 0; r < NK; ++r) {
+	for (int r = 0; r < 2 * NK; ++r) {
 		const int ci = mi[r];
-		if (ci >= 0 && ms[r] >= thr && !(REV && ci == a_row)) {      // REV: kk != k (matcher.cc:58)
+		if (!overflow && ci >= 0 && ms[r] >= thr && !(REV && ci == a_row)) {      // REV: kk != k (matcher.cc:58)
 			// insertion into ascending column order: distance ties resolve to the first index (matcher.cc:42-48)
 			int v = ci;
 #pragma unroll
-			for (int q = 0; q < NK; ++q) { const int o = c[q]; const bool sw = v < o; c[q] = sw ? v : o; v = sw ? o : v; }
+			for (int q = 0; q < NC; ++q) { const int o = c[q]; const bool sw = v < o; c[q] = sw ? v : o; v = sw ? o : v; }
 			++nc;
 		}
 	}
@@ -373,7 +464,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		if (h == 1) { w0 = v0; w1 = v1; w2 = v2; w3 = v3; }      // partial sums handed over below
 		int ccol = 0;
 #pragma unroll
-		for (int r = 0; r < NK; ++r) ccol = (cu == r) ? c[r] : ccol;
+		for (int r = 0; r < NC; ++r) ccol = (cu == r) ? c[r] : ccol;
 		if (act) {
 			const f32x4* py = (const f32x4*)(Y + (long long)ccol * 128 + 64 * h);
 #pragma unroll
@@ -406,20 +497,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
 	}
 #if OP_MATCH_EXPERIMENT == 9
-	if (tid == 0) { atomicAdd(&g_match_timers[6], clock64() - tlast); atomicAdd(&g_match_timers[7], 1ULL); }
+	if (tid == 0) { atomicAdd(&g_match_timers[6], clock64() - tlast); atomicAdd(&g_match_timers[7], 1ULL); atomicAdd(&g_match_timers[8], wall_clock64() - wall0); atomicAdd(&g_match_timers[9], clock64() - cyc0); atomicSub(&g_occ[okey], 1); }
 #endif
 }
 
 // rows whose NK ranked candidates all fell inside the error margin (near-duplicate descriptors):
-// exact full scan, one wavefront per row -- lane l scans columns l, l+64, ... with the sequential
-// update of matcher.cc:42-48; the lane states are merged so that the result is the one a single
-// ascending scan produces (first index on equal minima, second-smallest as a multiset).
+// exact full scan, one workgroup of four wavefronts per row -- thread t scans columns t, t+256, ... with
+// the sequential update of matcher.cc:42-48; the thread states are merged (lanes by shuffles, waves
+// through LDS) with an order-free operator, so that the result is the one a single ascending scan
+// produces (first index on equal minima, second-smallest as a multiset).
+struct ScanState { float mn, next_min; int min_idx; };
+__device__ __forceinline__ void scan_merge(ScanState& s, float omn, float onx, int oid) {
+	const bool mine = s.mn < omn || (s.mn == omn && s.min_idx < oid);
+	const float lo_next = mine ? s.next_min : onx, hi_min = mine ? omn : s.mn;
+	s.next_min = lo_next < hi_min ? lo_next : hi_min;
+	if (!mine) { s.mn = omn; s.min_idx = oid; }
+}
+// Groups the exact-scan queue by the image whose descriptors a row scans (counting sort, one workgroup; the
+// order inside a group does not matter).  k_match_slow then hands each XCD a contiguous eighth of the grouped
+// queue, so the rows that scan one image run on one XCD at about the same time and its descriptors come from
+// HBM once and from that XCD's L2 afterwards -- the scan reads a whole descriptor set per row and is
+// bandwidth-bound otherwise (5 TB/s measured with the queue in arrival order).
+constexpr int kOrderBins = 4096;
 template <bool REV>
-__global__ void __launch_bounds__(64) k_match_slow(MatchState S) {
+__global__ void __launch_bounds__(1024) k_slow_order(MatchState S, int nimg) {
+	__shared__ int s_cnt[kOrderBins];
+	__shared__ int s_part[16];
 	const int* q = REV ? S.slow_rev : S.slow_fwd;
 	int n = *(REV ? S.slow_rev_n : S.slow_fwd_n); n = n < S.slow_cap ? n : S.slow_cap;
-	const int lane = threadIdx.x;
-	for (int i = blockIdx.x; i < n; i += gridDim.x) {
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for (int i = tid; i < kOrderBins; i += 1024) s_cnt[i] = 0;
+	__syncthreads();
+	for (int i = tid; i < n; i += 1024) { const PairDesc pd = S.pairs[q[2 * i]]; atomicAdd(&s_cnt[REV ? pd.ia : pd.ib], 1); }
+	__syncthreads();
+	int c[4], sum = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { c[k] = s_cnt[tid * 4 + k]; sum += c[k]; }
+	int incl = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+	if (lane == 63) s_part[wave] = incl;
+	__syncthreads();
+	int base = incl - sum;
+	for (int w = 0; w < wave; ++w) base += s_part[w];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { s_cnt[tid * 4 + k] = base; base += c[k]; }
+	__syncthreads();
+	for (int i = tid; i < n; i += 1024) {
+		const int pair = q[2 * i]; const PairDesc pd = S.pairs[pair];
+		const int pos = atomicAdd(&s_cnt[REV ? pd.ia : pd.ib], 1);
+		S.slow_sorted[2 * pos] = pair; S.slow_sorted[2 * pos + 1] = q[2 * i + 1];
+	}
+}
+
+template <bool REV>
+__global__ void __launch_bounds__(256) k_match_slow(MatchState S, int grouped) {
+	__shared__ f32x4 s_x[32];
+	__shared__ float s_mn[4], s_nx[4];
+	__shared__ int s_id[4];
+	const int* q = grouped ? S.slow_sorted : (REV ? S.slow_rev : S.slow_fwd);
+	int n = *(REV ? S.slow_rev_n : S.slow_fwd_n); n = n < S.slow_cap ? n : S.slow_cap;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int per = n >> 3;
+	for (int lin = blockIdx.x; lin < n; lin += gridDim.x) {       // gridDim.x is a multiple of 8: lin & 7 is this workgroup's XCD
+		const int i = lin < per * 8 ? (lin & 7) * per + (lin >> 3) : lin;
 		const int pair = q[2 * i], a = q[2 * i + 1];
 		const PairDesc pd = S.pairs[pair];
 		const float* A = S.desc + (long long)pd.a_off * 128;
@@ -427,25 +568,47 @@ __global__ void __launch_bounds__(64) k_match_slow(MatchState S) {
 		const float* x = REV ? B + (long long)S.fb[pd.res_off + a] * 128 : A + (long long)a * 128;
 		const float* Y = REV ? A : B;
 		const int ky = REV ? pd.ka : pd.kb;
-		float mn = FLT_MAX, next_min = FLT_MAX; int min_idx = 0x7fffffff;
-		for (int kk = lane; kk < ky; kk += 64) {
+		if (tid < 32) s_x[tid] = ((const f32x4*)x)[tid];
+		__syncthreads();
+		ScanState st = {FLT_MAX, FLT_MAX, 0x7fffffff};
+		for (int kk = tid; kk < ky; kk += 256) {
 			if (REV && kk == a) continue;
-			const float d = euclidean_sqr_exact(x, Y + (long long)kk * 128);
-			if (d < mn) { next_min = mn; mn = d; min_idx = kk; }
-			else if (d < next_min) next_min = d;
+			// euclidean_sqr_exact with the row x in LDS and the column fetched sixteen 16-byte blocks at a time
+			const f32x4* py = (const f32x4*)(Y + (long long)kk * 128);
+			float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				f32x4 b[16];
+#pragma unroll
+				for (int t = 0; t < 16; ++t) b[t] = py[16 * half + t];
+#pragma unroll
+				for (int t = 0; t < 16; ++t) {
+					const f32x4 av = s_x[16 * half + t];
+					float d;
+					d = av.x - b[t].x; v0 += d * d;
+					d = av.y - b[t].y; v1 += d * d;
+					d = av.z - b[t].z; v2 += d * d;
+					d = av.w - b[t].w; v3 += d * d;
+				}
+			}
+			const float d = (v0 + v1) + (v2 + v3);
+			if (d < st.mn) { st.next_min = st.mn; st.mn = d; st.min_idx = kk; }
+			else if (d < st.next_min) st.next_min = d;
 		}
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) {
-			const float omn = __shfl_xor(mn, off), onx = __shfl_xor(next_min, off); const int oid = __shfl_xor(min_idx, off);
-			const bool mine = mn < omn || (mn == omn && min_idx < oid);
-			const float lo_next = mine ? next_min : onx, hi_min = mine ? omn : mn;
-			next_min = lo_next < hi_min ? lo_next : hi_min;
-			if (!mine) { mn = omn; min_idx = oid; }
+			const float omn = __shfl_xor(st.mn, off), onx = __shfl_xor(st.next_min, off); const int oid = __shfl_xor(st.min_idx, off);
+			scan_merge(st, omn, onx, oid);
 		}
-		if (lane == 0) {
-			if (!REV) finish_forward(S, pd, pair, a, mn, next_min, min_idx == 0x7fffffff ? -1 : min_idx);
-			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, pair, a, next_min < f ? next_min : f); }
+		if (lane == 0) { s_mn[wave] = st.mn; s_nx[wave] = st.next_min; s_id[wave] = st.min_idx; }
+		__syncthreads();
+		if (tid == 0) {
+#pragma unroll
+			for (int w = 1; w < 4; ++w) scan_merge(st, s_mn[w], s_nx[w], s_id[w]);
+			if (!REV) finish_forward(S, pd, pair, a, st.mn, st.next_min, st.min_idx == 0x7fffffff ? -1 : st.min_idx);
+			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, pair, a, st.next_min < f ? st.next_min : f); }
 		}
+		__syncthreads();
 	}
 }
 
@@ -476,7 +639,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		PairDesc& pd = pds[p];
 		pd.a_off = (int)fv.offsets[ia]; pd.ka = fv.counts[ia];
 		pd.b_off = (int)fv.offsets[ib]; pd.kb = fv.counts[ib];
-		pd.rev = rev;
+		pd.rev = rev; pd.ia = ia; pd.ib = ib;
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
 		if (pd.ka > 0 && pd.kb > 0)
 			for (int rb = 0; rb * 128 < pd.ka; ++rb) work.push_back({p, rb});
@@ -514,7 +677,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t o_fb = al(o_fnext + sizeof(float) * nres);
 	const size_t o_surv = al(o_fb + sizeof(int) * nres);
 	const size_t o_slow = al(o_surv + sizeof(int) * nres);
-	const size_t o_up = al(o_slow + sizeof(int) * 4 * (size_t)slow_cap);
+	const size_t o_up = al(o_slow + sizeof(int) * 6 * (size_t)slow_cap);       // forward queue, reverse queue, the grouped copy of the one being scanned
 	const size_t up_bytes = sizeof(PairDesc) * npairs + sizeof(WorkItem) * work.size();
 	const size_t arena_bytes = o_up + al(up_bytes);
 	char* arena = nullptr;
@@ -539,8 +702,9 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		S.gmax_bits = (const unsigned*)ctrl; S.pairs = (const PairDesc*)(arena + o_up);
 		S.fb = (int*)(arena + o_fb); S.fmn = (float*)(arena + o_fmn); S.fnext = (float*)(arena + o_fnext);
 		S.surv = (int*)(arena + o_surv); S.nsurv = ctrl + 3; S.mlist = d_mlist;
-		S.slow_fwd = (int*)(arena + o_slow); S.slow_rev = S.slow_fwd + 2 * (size_t)slow_cap;
+		S.slow_fwd = (int*)(arena + o_slow); S.slow_rev = S.slow_fwd + 2 * (size_t)slow_cap; S.slow_sorted = S.slow_fwd + 4 * (size_t)slow_cap;
 		S.slow_fwd_n = ctrl + 1; S.slow_rev_n = ctrl + 2; S.slow_cap = slow_cap;
+		const int grouped = fv.n <= kOrderBins;                         // the grouping kernel keeps one LDS counter per image
 		S.rr = cfg->MATCH_REJECT_NEXT_RATIO * cfg->MATCH_REJECT_NEXT_RATIO;   // matcher.cc:16
 		const WorkItem* d_work = (const WorkItem*)(arena + o_up + sizeof(PairDesc) * npairs);
 		{
@@ -554,7 +718,8 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 				ProfScope ps(ctx, "matcher mfma forward");
 				hipLaunchKernelGGL(k_match_sweep<false>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
 				MCHK(hipGetLastError());
-				hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(64), 0, st, S);
+				if (grouped) hipLaunchKernelGGL(k_slow_order<false>, dim3(1), dim3(1024), 0, st, S, fv.n);
+				hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(256), 0, st, S, grouped);
 				MCHK(hipGetLastError());
 			}
 			{
@@ -562,7 +727,8 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 				ProfScope ps(ctx, "matcher mfma reverse");
 				hipLaunchKernelGGL(k_match_sweep<true>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
 				MCHK(hipGetLastError());
-				hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(64), 0, st, S);
+				if (grouped) hipLaunchKernelGGL(k_slow_order<true>, dim3(1), dim3(1024), 0, st, S, fv.n);
+				hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(256), 0, st, S, grouped);
 				MCHK(hipGetLastError());
 			}
 		}
@@ -574,6 +740,9 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		MCHK(hipMemcpyAsync(h_ml, d_mlist, sizeof(int) * (1 + 3 * kHead), hipMemcpyDeviceToHost, st));
 		MCHK(hipMemcpyAsync(h_slow, (int*)(arena + o_ctrl) + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
 		MCHK(hipStreamSynchronize(st));
+#if OP_MATCH_EXPERIMENT == 9
+		fprintf(stderr, "[match trace] exact-scan rows: forward %d, reverse %d\n", h_slow[0], h_slow[1]);
+#endif
 		if (h_slow[0] > slow_cap || h_slow[1] > slow_cap) {
 			// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
 			// descriptors in one call): the rows beyond the queue were not matched -- never return that as OP_OK
@@ -628,9 +797,14 @@ done:
 #if OP_MATCH_EXPERIMENT == 9
 // timing experiment only: cycles of wave 0 per phase, summed over all workgroups since the last read
 int op_debug_match_timers(unsigned long long* out) {
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_timers), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-	unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_timers), sizeof(unsigned long long) * 10) != hipSuccess) return -1;
+	unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	return hipMemcpyToSymbol(HIP_SYMBOL(g_match_timers), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+int op_debug_match_occupancy(unsigned long long* out) {
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_occ_hist), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+	unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_occ_hist), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
 
