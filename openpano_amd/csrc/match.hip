@@ -124,20 +124,7 @@ __global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ de
 	if (threadIdx.x == 0) atomicMax(gmax_bits, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 }
 
-// running top-NK (descending score); the common case is the single rejecting compare.  NK = 4:
-// the insertion network runs for the whole wave whenever ANY lane inserts (most steps), so it is
-// kept short; rows whose 4 entries all tie within the error margin go to the exact full scan.
-constexpr int NK = 4;
-__device__ __forceinline__ void topk_insert(float (&ts)[NK], int (&ti)[NK], float s, int idx) {
-	if (!(s > ts[NK - 1])) return;
-#pragma unroll
-	for (int r = NK - 1; r >= 0; --r) {
-		const bool up = r > 0 && s > ts[r - 1];       // the new entry belongs above slot r: shift down
-		const float ns = up ? ts[r - 1] : s; const int ni = up ? ti[r - 1] : idx;
-		const bool here = s > ts[r];                  // slots below the insertion point are rewritten
-		ts[r] = here ? ns : ts[r]; ti[r] = here ? ni : ti[r];
-	}
-}
+constexpr int NK = 4;      // kept entries per lane half (descending); a half whose NK entries all tie within the error margin sends its row to the exact full scan
 
 // The sweep's running top-NK is kept on KEYS: the score with its low 4 mantissa bits replaced by the MFMA
 // register slot (0..15) it came from.  A key is still an ordinary float within 16 ulp of the score
@@ -228,17 +215,19 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 // One workgroup = 128 rows of X (4 waves x 32 rows, the split X fragments resident in VGPRs) against
 // all of Y, whose split rows stream through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
 // holding 16 scores of ONE X row (C/D layout: col = lane&31), which makes the running top-4 a
-// purely per-lane update; the two lane halves (k < 64 / k >= 64 of the row) are merged once at
-// the end.  MFMA scores (x.y - |y|^2/2 = const - d/2) only RANK columns.  The epilogue then
-// re-scores the <= 4 ranked candidates of every row with the reference's exact squared L2
+// purely per-lane update (on keys, above); the two lane halves of a row (columns i & 4 == 0 / != 0 of
+// every tile) exchange their lists once at the end.  The accumulators start from -|y|^2/2, so the MFMA
+// chain ends on the scores x.y - |y|^2/2 = const - d/2, which only RANK columns.  The epilogue then
+// re-scores the <= 6 ranked candidates of every row with the reference's exact squared L2
 // (feature/dist.cc:22-57: four stride-4 fp32 partial sums walked in order, (v0+v1)+(v2+v3)):
 // the row is still in registers, split across the two lane halves exactly at t = 16, so the
 // lower half walks t = 0..15, hands its four partial sums to the upper half, which walks
 // t = 16..31 -- candidates are software-pipelined through the two halves.  The candidate set is
-// provably complete: every column whose score is within E of the 2nd best is re-scored, where E
-// bounds twice the worst-case error of a score (dropped split terms 3 * 2^-18, 384 fp32
-// accumulations, the fp32 norm) plus the rounding of the reference's own fp32 distance; if all 4
-// kept entries fall inside the margin the row is queued for an exact full scan instead.
+// provably complete: every column whose key is within E of the row's 2nd best is re-scored, where E
+// bounds twice the worst-case error of a key (dropped split terms 3 * 2^-18, 385 fp32
+// accumulations, the fp32 norm, the 4 slot bits) plus the rounding of the reference's own fp32
+// distance; a row one of whose halves has all 4 kept entries inside the margin is queued for an
+// exact full scan instead.
 template <bool REV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
 	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
@@ -285,16 +274,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	// re-read its last row, their columns cannot rank because their |y|^2/2 is FLT_MAX.
 	uint4 st0, st1, st2, st3; float stage_ny = 0.f; bool stage_pad = false;
 	const int f_yr = tid >> 5, f_c4 = tid & 31;          // block e = tid + 256 r  ->  row f_yr + 8 r, column block f_c4
+	// 32-bit byte offsets from the (uniform) base of the Y split: the loads take the SGPR-base + VGPR-offset form,
+	// a row clamp is one v_min on the offset (op_match_pairs refuses sets of 4 M descriptors and more)
+	const char* ys_base = (const char*)YS;
+	const unsigned f_last = (unsigned)(ky - 1) * 512u + (unsigned)f_c4 * 16u;
+	const unsigned f_first = (unsigned)f_yr * 512u + (unsigned)f_c4 * 16u;
 	auto fetch_tile = [&](int t) {
-		const int r0 = t * 32 + f_yr, last = ky - 1;
-		const int g0 = r0 < last ? r0 : last, g1 = r0 + 8 < last ? r0 + 8 : last, g2 = r0 + 16 < last ? r0 + 16 : last, g3 = r0 + 24 < last ? r0 + 24 : last;
-		st0 = YS[(long long)g0 * 32 + f_c4];
-		st1 = YS[(long long)g1 * 32 + f_c4];
-		st2 = YS[(long long)g2 * 32 + f_c4];
-		st3 = YS[(long long)g3 * 32 + f_c4];
+		const unsigned o0 = f_first + (unsigned)t * 16384u;
+		const unsigned g0 = o0 < f_last ? o0 : f_last, g1 = o0 + 4096u < f_last ? o0 + 4096u : f_last,
+				g2 = o0 + 8192u < f_last ? o0 + 8192u : f_last, g3 = o0 + 12288u < f_last ? o0 + 12288u : f_last;
+		st0 = *(const uint4*)(ys_base + g0);
+		st1 = *(const uint4*)(ys_base + g1);
+		st2 = *(const uint4*)(ys_base + g2);
+		st3 = *(const uint4*)(ys_base + g3);
 		// the raw |y|^2 only: any arithmetic on it here would wait for the load at the top of the iteration
 		const int gy = t * 32 + (tid & 31);
-		stage_ny = ny[gy < ky ? gy : last];
+		stage_ny = ny[gy < ky ? gy : ky - 1];
 		stage_pad = gy >= ky;
 	};
 	auto commit_tile = [&](int buf) {
@@ -303,7 +298,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		*(uint4*)(d + 8 * YP) = st1;
 		*(uint4*)(d + 16 * YP) = st2;
 		*(uint4*)(d + 24 * YP) = st3;
-		if (tid < 32) s_nyh[buf][tid] = stage_pad ? FLT_MAX : 0.5f * stage_ny;   // padded columns can never rank
+		if (tid < 32) s_nyh[buf][tid] = stage_pad ? -FLT_MAX : -0.5f * stage_ny;   // -|y|^2/2: the accumulators START from it; padded columns can never rank
 	};
 
 	fetch_tile(0);
@@ -319,33 +314,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		const int buf = t & 1;
 		if (t + 1 < ntiles) fetch_tile(t + 1);
 		STAMP(0);
-		f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
-		// |y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h, fetched ahead of the MFMA
-		// chain (one LDS round trip instead of sixteen serialised ones in front of the top-4 updates)
-		f32x4 nyh[4];
+		// the accumulators start from -|y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h (four
+		// 16-byte LDS reads straight into the accumulator registers): the MFMA chain ends on the scores
+		f32x16 acc;
 #pragma unroll
-		for (int g = 0; g < 4; ++g) nyh[g] = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
+		for (int g = 0; g < 4; ++g) {
+			const f32x4 v = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
+			acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+		}
 #if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
 		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
 #else
-#if OP_MATCH_EXPERIMENT == 11 || OP_MATCH_EXPERIMENT == 13
-		__builtin_amdgcn_s_setprio(3);
-#endif
-#if OP_MATCH_EXPERIMENT == 12 || OP_MATCH_EXPERIMENT == 13
-		f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-		for (int kb = 0; kb < 8; ++kb) {
-			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
-			const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[kb]), bl = __builtin_bit_cast(bf16x8, xl[kb]);
-			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-			acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
-			if (kb & 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-			else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
-		}
-#pragma unroll
-		for (int reg = 0; reg < 16; ++reg) acc[reg] += acc2[reg];
-#else
+		// (raising the wave's priority over the chain, or splitting it over two accumulators, changes nothing:
+		// DESIGN.md section 6)
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
 			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
@@ -355,41 +337,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
 #endif
-#if OP_MATCH_EXPERIMENT == 11 || OP_MATCH_EXPERIMENT == 13
-		__builtin_amdgcn_s_setprio(0);
-#endif
-#endif
 #if OP_MATCH_EXPERIMENT == 9
 		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
 #endif
 		STAMP(1);
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
-		// (screening the 16 scores with wave ballots first and branching on the scalar masks was measured:
-		// no gain over the per-score compare + branch below)
-#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
 		const float old_keys[NK] = {ts[0], ts[1], ts[2], ts[3]};
-#endif
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
-			const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h; (void)i;
-			const float sc = acc[reg] - nyh[reg >> 2][reg & 3];
-#if OP_MATCH_EXPERIMENT == 1      // timing experiment: running maximum only, no top-4 network
-			if (sc > ts[0]) { ts[0] = sc; ti[0] = t * 32 + i; }
-#elif OP_MATCH_EXPERIMENT == 3    // timing experiment: scores are only folded into one value
-			ts[0] = fmaxf(ts[0], sc);
-#elif OP_MATCH_EXPERIMENT == 14   // timing experiment: branch-free top-4 VALUES (max + 3 med3 on keys carrying the register slot), no indices
-			{
-				const float key = __uint_as_float((__float_as_uint(sc) & ~15u) | (unsigned)reg);
-				const float n3 = __builtin_amdgcn_fmed3f(ts[2], ts[3], key), n2 = __builtin_amdgcn_fmed3f(ts[1], ts[2], key), n1 = __builtin_amdgcn_fmed3f(ts[0], ts[1], key);
-				ts[0] = __builtin_amdgcn_fmed3f(ts[0], key, __builtin_inff()); ts[1] = n1; ts[2] = n2; ts[3] = n3;
-			}
+#if OP_MATCH_EXPERIMENT == 3      // timing experiment: scores are only folded into one value
+			ts[0] = fmaxf(ts[0], acc[reg]);
 #else
-			topk_keys(ts, score_key(sc, reg));
+			topk_keys(ts, score_key(acc[reg], reg));
 #endif
 		}
-#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
 		topk_attribute(old_keys, ts, ti, t);          // ti[] holds TILE numbers until the sweep ends
-#endif
 		STAMP(2);
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		STAMP(3);
@@ -401,14 +363,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 #endif
 	// (tile, slot) -> column: slot reg of lane half h is column (reg & 3) + 8 (reg >> 2) + 4 h of its tile; never-filled
 	// entries (tile -1) and the padded columns of the last tile (score -FLT_MAX, they rank above nothing real) are no candidates
-#if OP_MATCH_EXPERIMENT == 0 || OP_MATCH_EXPERIMENT == 9
 #pragma unroll
 	for (int r = 0; r < NK; ++r) {
 		const int reg = (int)(__float_as_uint(ts[r]) & 15u);
 		const int col = ti[r] * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 		ti[r] = (ti[r] < 0 || col >= ky) ? -1 : col;
 	}
-#endif
 	// the two lane halves of an X row exchange their lists; both then derive the same candidate set
 #pragma unroll
 	for (int r = 0; r < NK; ++r) { s_ms[wave][j][h][r] = ts[r]; s_mi[wave][j][h][r] = ti[r]; }
@@ -641,21 +601,31 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		pd.b_off = (int)fv.offsets[ib]; pd.kb = fv.counts[ib];
 		pd.rev = rev; pd.ia = ia; pd.ib = ib;
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
-		if (pd.ka > 0 && pd.kb > 0)
-			for (int rb = 0; rb * 128 < pd.ka; ++rb) work.push_back({p, rb});
 	}
-	{	// Workgroups are handed to the 8 XCDs round-robin by index.  Re-order the list so that the row
-		// blocks of one pair (which stream the same Y set) run on ONE XCD at about the same time:
-		// Y then comes from HBM once and from that XCD's L2 for the other row blocks.
-		const size_t per = work.size() >> 3;
-		if (per > 0) {
-			std::vector<WorkItem> w2(work.size());
-			for (size_t lin = 0; lin < work.size(); ++lin)
-				w2[lin] = lin < per * 8 ? work[(lin & 7) * per + (lin >> 3)] : work[lin];
-			work.swap(w2);
+	{	// Workgroups are handed to the 8 XCDs round-robin by index.  The row blocks of one pair (which stream the
+		// same Y set) go to ONE XCD, back to back: Y then comes from HBM once and from that XCD's L2 for the other
+		// row blocks.  Pairs are dealt longest Y first to the XCD with the least work so far, so every XCD's
+		// queue runs from its longest workgroups to its shortest and the last round of the launch is short.
+		std::vector<int> order; order.reserve(npairs);
+		for (int p = 0; p < npairs; ++p) if (pds[p].ka > 0 && pds[p].kb > 0) order.push_back(p);
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pds[a].kb > pds[b].kb; });
+		std::vector<WorkItem> chunk[8]; long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int p : order) {
+			int c = 0;
+			for (int k = 1; k < 8; ++k) if (load[k] < load[c]) c = k;
+			const int nrb = (pds[p].ka + 127) / 128;
+			for (int rb = 0; rb < nrb; ++rb) chunk[c].push_back({p, rb});
+			load[c] += (long long)nrb * pds[p].kb;
 		}
+		size_t longest = 0, total_items = 0;
+		for (int c = 0; c < 8; ++c) { longest = std::max(longest, chunk[c].size()); total_items += chunk[c].size(); }
+		work.reserve(total_items);
+		for (size_t k = 0; k < longest; ++k)
+			for (int c = 0; c < 8; ++c) if (k < chunk[c].size()) work.push_back(chunk[c][k]);
 	}
 	if (res_rows >= (1LL << 30)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: too many rows in one call; split the pair list"); }
+	for (int i = 0; i < fv.n; ++i)
+		if (fv.counts[i] >= (1 << 22)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: an image with 4 M descriptors or more (the sweep addresses a descriptor set with 32-bit byte offsets)"); }
 	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
 	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
