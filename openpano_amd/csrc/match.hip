@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256) k_match_slow(MatchState S, int grouped) {
 #pragma unroll
 			for (int w = 1; w < 4; ++w) scan_merge(st, s_mn[w], s_nx[w], s_id[w]);
 			if (!REV) finish_forward(S, pd, pair, a, st.mn, st.next_min, st.min_idx == 0x7fffffff ? -1 : st.min_idx);
-			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, pair, a, st.next_min < f ? st.next_min : f); }
+			else { const float f = S.fnext[pd.res_off + a]; finish_reverse(S, pd, pair, a, st.mn < f ? st.mn : f); }   // matcher.cc:57-61: the MINIMUM over kk != k joins next_min
 		}
 		__syncthreads();
 	}

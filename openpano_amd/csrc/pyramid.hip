@@ -49,37 +49,56 @@ constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 __device__ __forceinline__ float src_tap(const float* s, long long i, const float*) { return s[i]; }
 __device__ __forceinline__ float src_tap(const unsigned char* s, long long i, const float* lut) { return lut[s[i]]; }
 
+// s / 3.f (lib/imgproc.cc:245) as (float)((double)s * (1.0 / 3.0)): the double product is within 2^-52 of s / 3, and s / 3
+// is never that close to a rounding boundary of fp32 (3 * midpoint is an odd 26..27-bit integer multiple of the grid, no fp32
+// number), so this IS the correctly rounded quotient -- three VALU operations instead of the ten of an IEEE fp32 division.
+__device__ __forceinline__ float third(float s) { return (float)((double)s * (1.0 / 3.0)); }
+
+constexpr int TR = 24, TC = 72;               // per-workgroup coordinate tables (rows, columns)
+
 template <typename SrcT>
 __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work) {
 	__shared__ float s_rgb[3][(WR + 1) * WP];
 	__shared__ float s_lut[256];
+	// resize_coord() is separable: the (source index, weight) of every row and of every column of the tile is computed
+	// once per workgroup and read back per pixel (the kernel is bound by VALU issue, and the two resize_coord calls
+	// were a third of a pixel's instructions)
+	__shared__ int s_ri[TR], s_ci[TC];
+	__shared__ float s_rw[TR], s_cw[TC];
+	__shared__ long long s_ro[TR];            // working tile: element offset of the source row
 	const int img = blockIdx.z;
 	const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WR;
 	const int tid = threadIdx.x;
 	const SrcT* src = (const SrcT*)p.srcs[img];
-	if (sizeof(SrcT) == 1) {      // (float)byte / 255.0: float -> double, IEEE division, round to float
-		s_lut[tid] = (float)((double)(float)tid / 255.0);
-		__syncthreads();
-	}
+	if (sizeof(SrcT) == 1) s_lut[tid] = (float)((double)(float)tid / 255.0);      // (float)byte / 255.0: float -> double, IEEE division, round to float
 	// working-image tile: lib/imgproc.cc:22-80 on the source
 	{
 		const float fx = (float)p.wh / (float)p.sh, fy = (float)p.ww / (float)p.sw;
 		const float ifx = 1.f / fx, ify = 1.f / fy;
+		if (tid < WR + 1) {
+			int sx = -1; float rx = 0.f;
+			if (ty0 + tid < p.wh) resize_coord(ty0 + tid, ifx, p.sh, sx, rx);
+			s_ri[tid] = sx; s_rw[tid] = rx; s_ro[tid] = (long long)sx * p.sw * 3;
+		} else if (tid >= 64 && tid < 64 + WT + 1) {
+			const int c = tid - 64;
+			int sy = -1; float ry = 0.f;
+			if (tx0 + c < p.ww) resize_coord(tx0 + c, ify, p.sw, sy, ry);
+			s_ci[c] = sy < 0 ? -1 : sy * 3; s_cw[c] = ry;
+		}
+		__syncthreads();
 		for (int e = tid; e < (WR + 1) * (WT + 1); e += 256) {
 			const int r = e / (WT + 1), c = e % (WT + 1);
-			const int row = ty0 + r, col = tx0 + c;
+			const int sx = s_ri[r], sy3 = s_ci[c];
 			float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-			if (row < p.wh && col < p.ww) {
-				int sx, sy; float rx, ry;
-				resize_coord(row, ifx, p.sh, sx, rx);
-				resize_coord(col, ify, p.sw, sy, ry);
+			if (sx >= 0 && sy3 >= 0) {
+				const float rx = s_rw[r], ry = s_cw[c];
 				const float irx = 1.0f - rx, iry = 1.0f - ry;
-				const long long i0 = ((long long)sx * p.sw + sy) * 3, i1 = i0 + (long long)p.sw * 3;
+				const long long i0 = s_ro[r] + sy3, i1 = i0 + (long long)p.sw * 3;
 				v0 = bilerp(src_tap(src, i0, s_lut), src_tap(src, i0 + 3, s_lut), src_tap(src, i1, s_lut), src_tap(src, i1 + 3, s_lut), rx, irx, ry, iry);
 				v1 = bilerp(src_tap(src, i0 + 1, s_lut), src_tap(src, i0 + 4, s_lut), src_tap(src, i1 + 1, s_lut), src_tap(src, i1 + 4, s_lut), rx, irx, ry, iry);
 				v2 = bilerp(src_tap(src, i0 + 2, s_lut), src_tap(src, i0 + 5, s_lut), src_tap(src, i1 + 2, s_lut), src_tap(src, i1 + 5, s_lut), rx, irx, ry, iry);
 				if (write_work && r < WR && c < WT) {
-					float* dst = p.work + (((long long)img * p.wh + row) * p.ww + col) * 3;
+					float* dst = p.work + (((long long)img * p.wh + ty0 + r) * p.ww + tx0 + c) * 3;
 					dst[0] = v0; dst[1] = v1; dst[2] = v2;
 				}
 			}
@@ -88,13 +107,13 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 	}
 	__syncthreads();
 	float* ws = p.ws + (long long)img * p.ws_stride;
-	// octave 0: grey of the working tile (lib/imgproc.cc:245)
-	for (int e = tid; e < WR * WT; e += 256) {
-		const int r = e / WT, c = e % WT;
-		const int row = ty0 + r, col = tx0 + c;
-		if (row < p.wh && col < p.ww)
-			ws[plane_off_grey(p.oct[0]) + (long long)row * p.ww + col] =
-				(s_rgb[0][r * WP + c] + s_rgb[1][r * WP + c] + s_rgb[2][r * WP + c]) / 3.f;
+	// octave 0: grey of the working tile (lib/imgproc.cc:245); thread = column, rows dealt to the four waves
+	{
+		const int c = tid & (WT - 1), col = tx0 + c;
+		float* g0 = ws + plane_off_grey(p.oct[0]) + (long long)ty0 * p.ww + col;
+		if (col < p.ww)
+			for (int r = tid >> 6; r < WR && ty0 + r < p.wh; r += 4)
+				g0[(long long)r * p.ww] = third(s_rgb[0][r * WP + c] + s_rgb[1][r * WP + c] + s_rgb[2][r * WP + c]);
 	}
 	// octaves 1..: pixels whose top-left tap (sx, sy) lies in this tile
 	for (int o = 1; o < p.noct; ++o) {
@@ -107,23 +126,46 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 		r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
 		r_hi = r_hi > od.h ? od.h : r_hi; c_hi = c_hi > od.w ? od.w : c_hi;
 		const int nr = r_hi - r_lo, nc = c_hi - c_lo;
-		if (nr <= 0 || nc <= 0) continue;
+		if (nr <= 0 || nc <= 0) continue;                   // uniform over the workgroup
+		const bool tables = nr <= TR && nc <= TC;           // always, as long as an octave is not larger than the working image
+		__syncthreads();                                    // the previous user of the tables is done
+		if (tables) {
+			if (tid < nr) {
+				int sx; float rx;
+				resize_coord(r_lo + tid, ifx, p.wh, sx, rx);
+				const int lr = sx - ty0;
+				s_ri[tid] = (lr >= 0 && lr < WR) ? lr : -1; s_rw[tid] = rx;
+			} else if (tid >= 64 && tid - 64 < nc) {
+				int sy; float ry;
+				resize_coord(c_lo + tid - 64, ify, p.ww, sy, ry);
+				const int lc = sy - tx0;
+				s_ci[tid - 64] = (lc >= 0 && lc < WT) ? lc : -1; s_cw[tid - 64] = ry;
+			}
+		}
+		__syncthreads();
+		float* go = ws + plane_off_grey(od);
 		const float inv_nc = 1.0f / (float)nc;            // e / nc through a float reciprocal (e < 2^16): an integer division costs ~40 VALU
 		for (int e = tid; e < nr * nc; e += 256) {
 			int q = (int)(((float)e + 0.5f) * inv_nc), rem = e - q * nc;
 			if (rem < 0) { --q; rem += nc; } else if (rem >= nc) { ++q; rem -= nc; }
 			const int dr = r_lo + q, dc = c_lo + rem;
-			int sx, sy; float rx, ry;
-			resize_coord(dr, ifx, p.wh, sx, rx);
-			resize_coord(dc, ify, p.ww, sy, ry);
-			const int lr = sx - ty0, lc = sy - tx0;
-			if (lr < 0 || lr >= WR || lc < 0 || lc >= WT) continue;
+			int lr, lc; float rx, ry;
+			if (tables) { lr = s_ri[q]; lc = s_ci[rem]; rx = s_rw[q]; ry = s_cw[rem]; }
+			else {
+				int sx, sy;
+				resize_coord(dr, ifx, p.wh, sx, rx);
+				resize_coord(dc, ify, p.ww, sy, ry);
+				lr = sx - ty0; lc = sy - tx0;
+				if (lr >= WR) lr = -1;
+				if (lc >= WT) lc = -1;
+			}
+			if (lr < 0 || lc < 0) continue;
 			const float irx = 1.0f - rx, iry = 1.0f - ry;
 			const int b = lr * WP + lc;
 			const float r = bilerp(s_rgb[0][b], s_rgb[0][b + 1], s_rgb[0][b + WP], s_rgb[0][b + WP + 1], rx, irx, ry, iry);
 			const float g = bilerp(s_rgb[1][b], s_rgb[1][b + 1], s_rgb[1][b + WP], s_rgb[1][b + WP + 1], rx, irx, ry, iry);
 			const float bl = bilerp(s_rgb[2][b], s_rgb[2][b + 1], s_rgb[2][b + WP], s_rgb[2][b + WP + 1], rx, irx, ry, iry);
-			ws[plane_off_grey(od) + (long long)dr * od.w + dc] = (r + g + bl) / 3.f;   // lib/imgproc.cc:245
+			go[(long long)dr * od.w + dc] = third(r + g + bl);   // lib/imgproc.cc:245
 		}
 	}
 }

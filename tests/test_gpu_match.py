@@ -81,6 +81,69 @@ def test_edge_cases(ctx, oracle, cfg):
     f.free()
 
 
+def test_near_ties_across_tiles_and_lane_halves(ctx, oracle, cfg):
+    """The sweep keeps a top-4 of KEYS per lane half (column & 4 of every 32-column tile selects the half) and
+    re-scores every kept entry within the error margin of the row's 2nd best.  Near-copies of a row (inside the
+    margin: |delta d^2| of a few units on |x|^2 = 512^2) are planted at chosen columns -- same tile / different
+    tiles, same half / both halves, 2 to 6 copies (up to 3 + 3 candidates; 4 in one half = exact full scan) --
+    and the match sets must equal the exact matcher's, forward and reverse."""
+    from openpano_amd import hip
+    rng = np.random.default_rng(77)
+    a = np.load(os.path.join(HERE, "golden", "sift_d_500x700.npz"))["desc"]
+    x = a[:96].copy()
+    ky = 32 * 9
+    y = a[200:200 + ky].copy()
+    plans = [
+        [0, 1],                      # two copies, same tile, same half
+        [0, 4],                      # same tile, the two halves
+        [3, 32 + 3, 64 + 3],         # three tiles, same slot, same half
+        [2, 6, 32 + 9, 64 + 13],     # two per half
+        [1, 2, 3, 5, 6, 7],          # 3 + 3 in one tile
+        [0, 1, 2, 3],                # four in one half: overflow -> exact scan
+        [8, 40, 72, 104, 136, 168],  # six tiles, one half
+        [31, 63, 95, 287],           # last slots, last tile
+    ]
+    for r in range(len(x)):
+        cols = [(c + 32 * (r % 3)) % ky for c in plans[r % len(plans)]]
+        for k, c in enumerate(cols):
+            y[c] = x[r]
+            if k > 0 or r % 2:       # exact duplicate for even rows' first copy, otherwise a near-copy
+                j = rng.integers(0, 128, 3)
+                y[c, j] = np.maximum(y[c, j] + rng.choice([-0.25, 0.25, 0.5], 3).astype(np.float32), 0)
+    f = hip.Features.from_host(ctx, [x, y, y[:40], x[:5]])
+    pairs = [(0, 1), (1, 0), (2, 0), (0, 2), (3, 1), (1, 3)]
+    sets = [x, y, y[:40], x[:5]]
+    got = hip.match_pairs(ctx, cfg, f, pairs)
+    for (i, j), g in zip(pairs, got):
+        want = oracle.match_exact(sets[i], sets[j])
+        assert np.array_equal(g, want), (i, j, len(g), len(want))
+    f.free()
+
+
+def test_reverse_exact_scan_uses_the_minimum(ctx, oracle, cfg):
+    """The second ratio test compares the match's distance with the MINIMUM reverse distance over kk != k
+    (matcher.cc:57-61).  A row whose reverse pass takes the exact full scan (four near-ties in one lane half) and
+    whose smallest and second-smallest reverse distances straddle the ratio threshold: rounds 1-2 passed the
+    second-smallest there and accepted one match in 740 k too many on the config-5 job (pair (2, 94))."""
+    from openpano_amd import hip
+    a_all = np.load(os.path.join(HERE, "golden", "sift_d_500x700.npz"))["desc"]
+    A = a_all[:60].copy(); B = a_all[100:180].copy()
+    v = a_all[300].copy()
+    bstar = v.copy(); bstar[5] += np.float32(np.sqrt(40.0))             # d2(a, b*) = 40
+    A[16] = v; B[33] = bstar
+    for k, (row, m) in enumerate([(0, 50.0), (1, 70.0), (2, 72.0), (3, 74.0), (8, 76.0)]):   # near-copies of b* in lane half 0
+        A[row] = bstar; A[row][20 + k] += np.float32(np.sqrt(m))
+    sets = [A, B]
+    f = hip.Features.from_host(ctx, sets)
+    for (i, j) in [(0, 1), (1, 0)]:
+        got = hip.match_pairs(ctx, cfg, f, [(i, j)])[0]
+        want = oracle.match_exact(sets[i], sets[j])
+        assert np.array_equal(got, want), (i, j, got.tolist(), want.tolist())
+    # the construction does what it says: 0.64 * 50 < 40 <= 0.64 * 70, so row 16 must be rejected
+    assert not any(g[0] == 16 and g[1] == 33 for g in hip.match_pairs(ctx, cfg, f, [(0, 1)])[0])
+    f.free()
+
+
 def test_full_size_properties(ctx, oracle, cfg):
     """config-4 sized descriptor sets: symmetry + spot oracle checks"""
     from openpano_amd import hip
