@@ -88,3 +88,36 @@ long orc_match_pairs_batch(const orc_sift_cfg* cfg, const float* desc, const int
 	free(offs);
 	return total;
 }
+
+/* the same loop, keeping a per-pair digest: count[p] = #matches, digest[p] = sum over the pair's matches of a 64-bit
+ * mix of (first, second) -- order-free, so a device result list can be digested the same way and compared pair by
+ * pair at sizes where holding every list twice is pointless (8128 pairs of the config-5 job) */
+static unsigned long long mix64(unsigned long long x) {
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+	return x;
+}
+unsigned long long orc_match_digest(const int* pairs2, int n) {
+	unsigned long long d = 0;
+	for (int k = 0; k < n; ++k) d += mix64(((unsigned long long)(unsigned)pairs2[2 * k] << 32) | (unsigned)pairs2[2 * k + 1]);
+	return d;
+}
+long orc_match_pairs_digest(const orc_sift_cfg* cfg, const float* desc, const int* counts, int n, const int* pairs, int npairs,
+		int nthreads, int* count, unsigned long long* digest) {
+	long* offs = (long*)malloc(sizeof(long) * (n + 1));
+	offs[0] = 0;
+	for (int i = 0; i < n; ++i) offs[i + 1] = offs[i] + counts[i];
+	long total = 0;
+	omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic) reduction(+:total)
+	for (int p = 0; p < npairs; ++p) {
+		const int i = pairs[2 * p], j = pairs[2 * p + 1];
+		const int mn = counts[i] < counts[j] ? counts[i] : counts[j];
+		int* out = (int*)malloc(sizeof(int) * 2 * (mn > 0 ? mn : 1));
+		count[p] = orc_match_exact(cfg, desc + offs[i] * 128, counts[i], desc + offs[j] * 128, counts[j], out);
+		digest[p] = orc_match_digest(out, count[p]);
+		total += count[p];
+		free(out);
+	}
+	free(offs);
+	return total;
+}

@@ -78,6 +78,9 @@ float orc_euclidean_sqr(const float* x, const float* y, int n, float now_thres);
 int orc_match_exact(const orc_sift_cfg* cfg, const float* d1, int n1, const float* d2, int n2, int* out_pairs);
 
 long orc_match_pairs_batch(const orc_sift_cfg* cfg, const float* desc, const int* counts, int n, const int* pairs, int npairs, int nthreads);
+unsigned long long orc_match_digest(const int* pairs2, int n);
+long orc_match_pairs_digest(const orc_sift_cfg* cfg, const float* desc, const int* counts, int n, const int* pairs, int npairs,
+		int nthreads, int* count, unsigned long long* digest);
 
 /* ---- RANSAC: TransformEstimation::get_transform (stitch/transform_estimate.cc:26-218), seed injected ---- */
 int orc_ransac(const int* match, int m, const double* kp1, int nk1, const double* kp2, int nk2,

@@ -164,6 +164,10 @@ class Oracle(_StagedBase):
 
         lib.orc_match_pairs_batch.restype = C.c_long
         lib.orc_match_pairs_batch.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int]
+        lib.orc_match_digest.restype = C.c_ulonglong
+        lib.orc_match_digest.argtypes = [_i32p, C.c_int]
+        lib.orc_match_pairs_digest.restype = C.c_long
+        lib.orc_match_pairs_digest.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, _i32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
         lib.orc_blend_prepare.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_void_p, _f64p, _f64p]
         lib.orc_blend_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.orc_blend_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p]
@@ -295,6 +299,19 @@ class Oracle(_StagedBase):
         counts = np.array([len(d) for d in descs], np.int32)
         pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
         return self.lib.orc_match_pairs_batch(self._cp(), flat.reshape(-1), counts, len(descs), pr.reshape(-1), len(pr), nthreads)
+
+    def match_pairs_digest(self, descs, pairs, nthreads):
+        """exact matcher over a pair list on `nthreads` host cores -> (#matches per pair, order-free digest per pair)"""
+        flat = np.ascontiguousarray(np.concatenate(descs), np.float32)
+        counts = np.array([len(d) for d in descs], np.int32)
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        cnt = np.zeros(len(pr), np.int32); dig = np.zeros(len(pr), np.uint64)
+        self.lib.orc_match_pairs_digest(self._cp(), flat.reshape(-1), counts, len(descs), pr.reshape(-1), len(pr), nthreads, cnt, dig)
+        return cnt, dig
+
+    def match_digest(self, pairs2):
+        p = np.ascontiguousarray(np.asarray(pairs2, np.int32).reshape(-1, 2))
+        return self.lib.orc_match_digest(p.reshape(-1), len(p))
 
     def euclidean_sqr(self, x, y, thres=np.float32(3.4e38)):
         return self.lib.orc_euclidean_sqr(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), len(x), thres)

@@ -168,3 +168,35 @@ def test_config5_shaped_job(ctx, oracle, cfg):
     same = [len(lists[k]) for k, (i, j) in enumerate(pairs) if i // 8 == j // 8]
     assert np.median(same) > 50
     mh.free(); feats.free()
+
+
+def test_config5_whole_match_job_digest(ctx, oracle, cfg):
+    """The whole config-5 match job on the device -- 128 device-resident 4000x3000 images, K ~ 4 k descriptors each,
+    all 8128 pairs in one call -- checked against the exact matcher on the host cores pair by pair (match count +
+    order-free digest of the index pairs).  By default a seeded sample of 320 of the 8128 pairs is checked (the
+    oracle needs ~1 core-second per pair); OPENPANO_FULL_C5=1 checks all of them (8 minutes on the GPU box's
+    host: profiles/r02_config5_all_pairs_digest.txt holds that run).  The full check is what found the
+    one-in-740 k reverse exact-scan error of rounds 1-2."""
+    import torch
+    from openpano_amd import hip
+    n = 128
+    dev_imgs = synth.config5_views(range(n), torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    f = hip.SiftCall(ctx, cfg, [(t.data_ptr(), 3000, 4000, "u8") for t in dev_imgs])()
+    del dev_imgs
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    got = hip.match_pairs(ctx, cfg, f, pairs)
+    assert sum(len(g) for g in got) > 500000
+    descs = [f.get(i)[0] for i in range(n)]
+    f.free()
+    if os.environ.get("OPENPANO_FULL_C5") == "1":
+        sel = list(range(len(pairs)))
+    else:
+        rng = np.random.default_rng(5)
+        same = [k for k, (i, j) in enumerate(pairs) if i // 8 == j // 8]          # overlapping views: hundreds of matches each
+        sel = sorted(set(rng.choice(same, 96, replace=False).tolist()) | set(rng.choice(len(pairs), 224, replace=False).tolist()))
+    cnt, dig = oracle.match_pairs_digest(descs, [pairs[k] for k in sel], os.cpu_count() or 8)
+    assert int(cnt.sum()) > 10000
+    bad = [(pairs[k], len(got[k]), int(c)) for k, c, d in zip(sel, cnt, dig)
+           if len(got[k]) != c or oracle.match_digest(got[k]) != int(d)]
+    assert not bad, bad[:10]
