@@ -26,7 +26,10 @@ def _mfma_roofline(prof, flops):
             "unit": "TFLOP/s", "frac": 3.0 * alg / 2500.0, "traffic": None,
             "dtype": "bf16 x3 split, fp32 accumulate; exact fp32 re-score decides",
             "algorithmic_tflops": alg, "algorithmic_over_fp32_mfma_peak": alg / 157.3,
-            "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms}
+            "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms,
+            # the clock under matrix load depends on the operand data: bf16 operands like split descriptors sustain
+            # 1.93 PFLOP/s on 50 ms launches of nothing but MFMAs (scripts/ubench/mfma_power.hip)
+            "data_ceiling": 1930.0, "frac_of_data_ceiling": 3.0 * alg / 1930.0}
 
 
 def _reduce(dist, dev, tmax_vals, sum_vals):
