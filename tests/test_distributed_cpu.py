@@ -1,9 +1,11 @@
 """CPU, world_size 2 over gloo: the descriptor all-gather and the pair partition that the
-multi-GPU path uses (RCCL on the GPU box) reconstruct one consistent global job."""
+multi-GPU path uses (RCCL on the GPU box) reconstruct one consistent global job; the whole sharded job at world 2
+and at world 3 (ragged shards) against the single-rank job."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -125,11 +127,13 @@ def _job_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_job_world2_equals_single_rank():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_job_equals_single_rank(world):
+    """world 2: the even deal; world 3: 5 images over 3 ranks (2 + 2 + 1) and 10 pairs (ragged shards, a rank
+    with a single image) -- every rank must end with the single-rank job's results"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     single = _run_job(1)                     # no process group: the world-1 path of ShardedJob
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -142,11 +146,13 @@ def test_sharded_job_world2_equals_single_rank():
         assert p.exitcode == 0
     k1, ktot1, counts1, pairs1, out1 = single
     assert k1 == ktot1 and len(pairs1) == 10 and min(counts1) > 30
-    (_, ka, kta, ca, pa, oa), (_, kb, ktb, cb, pb, ob) = res
-    assert ka + kb == kta == ktb == ktot1                 # SIFT sharded by image, nothing lost
-    assert ca == cb == counts1                            # the exchanged table is in global image order
-    assert sorted(pa + pb) == pairs1 and not (set(pa) & set(pb))
-    assert oa == ob                                       # every rank holds the whole job after the gather
+    assert sum(r[1] for r in res) == ktot1                # SIFT sharded by image, nothing lost
+    assert all(r[2] == ktot1 and r[3] == counts1 for r in res)   # the exchanged table is in global image order
+    allp = [p for r in res for p in r[4]]
+    assert sorted(allp) == pairs1 and len(set(allp)) == len(allp)         # a partition of the pair list
+    assert all(len(r[4]) > 0 for r in res)
+    oa = res[0][5]
+    assert all(r[5] == oa for r in res)                   # every rank holds the whole job after the gather
     assert sorted(oa) == sorted(out1)
     nok = 0
     for p in out1:                                        # match sets, RANSAC decision / confidence / homography: identical
