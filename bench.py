@@ -535,14 +535,15 @@ def main():
         if (world > 1 or dist is not None) and args.scaling == "weak" and not args.no_strong:      # also under OPENPANO_FORCE_DIST: the path must have run on hardware
             out["strong_config4"] = run_strong_job(hip, ctx, cfg, "config4", args, dist, dev, rank, world, barrier, log)
         if not args.no_config5:
-            out["config5"] = run_strong_job(hip, ctx, cfg, "config5", args, dist, dev, rank, world, barrier, log)
+            out["config5"] = run_strong_job(hip, ctx, cfg, "config5", args, dist, dev, rank, world, barrier, log,
+                                            parity=(rank == 0 and world == 1 and not args.no_cpu_baseline))
 
     # ---------------- CPU baseline + parity of the timed run (rank 0, N=1 only) ----------------
     rc = 0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t0 = time.perf_counter()
         out["parity"] = parity_check(hip, ctx, cfg, views, feats, log)
-        out["parity_checked"] = bool(out["parity"]["ok"])
+        out["parity_checked"] = bool(out["parity"]["ok"]) and bool(out.get("config5", {}).get("parity", {"ok": True})["ok"])
         out["cpu_baseline"] = cpu_baseline(cfg, views, log)
         if out.get("match"):
             out["match"]["cpu_baseline"] = match_cpu_baseline(cfg, feats, log)

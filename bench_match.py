@@ -102,7 +102,65 @@ def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, 
     return res
 
 
-def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, log):
+def job_parity(hip, ctx, cfg, job, d_imgs, u8, shapes, log, npairs_sample=96):
+    """Outside every timed region (N = 1): the job the timed pass just ran, against the CPU oracle --
+    descriptors and coordinates of EVERY image (CRC of the whole set), and for a seeded sample of pairs (half of them
+    overlapping views with hundreds of matches) the match set (count + order-free digest), the RANSAC winner, its
+    inlier count, the accepted flag and the homography.  -> dict with ok = everything bit-identical."""
+    import os
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from checkers import Oracle
+    orc = Oracle(cfg)
+    nt = min(64, os.cpu_count() or 1)
+    n = job.n
+    tab = job.tab
+
+    def host_f32(i):
+        a = d_imgs[i].cpu().numpy()
+        return (a.astype(np.float64) / 255.0).astype(np.float32) if u8 else a
+    with ThreadPoolExecutor(nt) as ex:
+        want = list(ex.map(lambda i: orc.detect_feature(host_f32(i)), range(n)))
+    got = [tab.get(i) for i in range(n)]
+    bad_img = [i for i in range(n) if not (np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]))]
+    pairs = job.my_pairs
+    rng = np.random.default_rng(5)
+    same = [k for k, (i, j) in enumerate(pairs) if i // 8 == j // 8] if u8 else []
+    half = min(len(same), npairs_sample // 2)
+    sel = set(rng.choice(same, half, replace=False).tolist()) if half else set()
+    sel |= set(rng.choice(len(pairs), min(len(pairs), npairs_sample - half), replace=False).tolist())
+    sel = sorted(sel)
+    lists = job.lists
+    cnt, dig = orc.match_pairs_digest([w[0] for w in want], [pairs[k] for k in sel], os.cpu_count() or 8)
+    bad_match = [list(pairs[k]) for k, c, d in zip(sel, cnt, dig) if len(lists[k]) != int(c) or orc.match_digest(lists[k]) != int(d)]
+    seeds = job.seeds(1)
+    res = hip.ransac_pairs(ctx, cfg, tab, job.mh, pairs, shapes, seeds=seeds)
+
+    def one(k):
+        i, j = pairs[k]
+        return orc.ransac(lists[k], want[i][1], want[j][1], shapes[i], shapes[j], seeds[k])
+    with ThreadPoolExecutor(nt) as ex:
+        wr = list(ex.map(one, sel))
+    bad_ransac = []
+    for k, w in zip(sel, wr):
+        g = res[k]
+        same_r = (g["best_hyp"] == w["best_hyp"] and g["best_count"] == w["best_count"] and g["ok"] == w["ok"] and g["confidence"] == w["confidence"]
+                  and np.array_equal(g["inliers"], w["inliers"]) and (not w["ok"] or np.array_equal(g["homo"], w["homo"])))
+        if not same_r:
+            bad_ransac.append(list(pairs[k]))
+    out = {"checked": True, "images": n, "descriptors": int(sum(len(w[0]) for w in want)), "images_differing": bad_img,
+           "descriptor_crc32": zlib.crc32(b"".join(np.ascontiguousarray(g[0]).tobytes() for g in got)),
+           "oracle_descriptor_crc32": zlib.crc32(b"".join(np.ascontiguousarray(w[0]).tobytes() for w in want)),
+           "pairs": len(sel), "matches": int(cnt.sum()), "longest_match_list": int(max((len(lists[k]) for k in sel), default=0)),
+           "pairs_differing": bad_match, "ransac_pairs": len(sel), "ransac_accepted": int(sum(1 for w in wr if w["ok"])),
+           "ransac_inliers": int(sum(len(w["inliers"]) for w in wr if w["ok"])), "ransac_pairs_differing": bad_ransac,
+           "ok": not bad_img and not bad_match and not bad_ransac}
+    if not out["ok"]:
+        log(f"PARITY FAILURE ({'config 5' if u8 else 'job'}): images {bad_img}, match pairs {bad_match}, ransac pairs {bad_ransac}")
+    return out
+
+
+def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, log, parity=False):
     """ONE job dealt over the N ranks (strong scaling), one warm pass + one timed pass with a barrier
     between phases: SIFT on the local shard, feature all-gather, match + RANSAC on this rank's share
     of the pair list, result gather.
@@ -172,6 +230,10 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
            "match_stage_ms": {x: round(v, 4) for x, v in prof.items()},
            "match_roofline": _mfma_roofline(prof, flops),
            "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
+    if parity and world == 1:
+        t0 = time.perf_counter()
+        res["parity"] = job_parity(hip, ctx, cfg, job, d_imgs, kind == "config5", shapes, log)
+        log(f"strong {kind}: parity of the timed job against the oracle took {time.perf_counter() - t0:.1f} s -> ok={res['parity']['ok']}")
     job.close()
     if eng._feats is not None:
         eng._feats.free(); eng._feats = None

@@ -166,12 +166,20 @@ int op_debug_set_raw_capacity(op_ctx* ctx, int cap);
  * reference's summation order (feature/dist.cc:22-57) decides.
  * ===================================================================================== */
 typedef struct op_matches op_matches;
-/* pairs: npairs x 2 image indices (i, j) into f */
+/* pairs: npairs x 2 image indices (i, j) into f.  The result stays in HBM -- per image pair a list of
+ * <idx in image i, idx in image j> sorted by (first, second) (MatchData, matcher.hh:14-25), pairs back to back in
+ * the order of `pairs` -- where op_ransac_pairs reads it; the call itself brings back the per-pair counts only.
+ * An op_matches must not outlive the context it was made with. */
 int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f,
 		const int* pairs, int npairs, op_matches** out);
 int op_matches_count(const op_matches* m, int p);
-/* pairs of <idx in image i, idx in image j> sorted by (first, second) (MatchData, matcher.hh:14-25) */
+/* the list of pair p on the host; the first copy fetches the whole job's lists from the device (one D2H),
+ * later ones are lookups.  Thread-safe (PairWiseMatcher::match is called concurrently, stitcher.cc:106-109). */
 int op_matches_copy(const op_matches* m, int p, int* idx_pairs);
+/* every list at once: idx_pairs = total x 2 ints (may be NULL), offsets = npairs + 1 entries (may be NULL) */
+int op_matches_copy_all(const op_matches* m, int* idx_pairs, int64_t* offsets);
+/* the device-resident flat list (total x 2 int32), NULL when the lists were wrapped from host arrays */
+const int* op_matches_device_list(const op_matches* m);
 int64_t op_matches_total(const op_matches* m);
 /* wrap host match lists (npairs lists of counts[p] <first, second> pairs): debug / test entry */
 int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out);
@@ -203,7 +211,9 @@ int op_match_pairs_multi(op_group* g, const op_config* cfg, const op_features* f
  * (stitch/transform_estimate.hh:22-31, transform_estimate.cc:26-218) for every pair at once.
  * pairs / m must be the pair list and result of op_match_pairs (match p belongs to pairs[p]);
  * keypoint coordinates come from f (centred original-image pixels); shapes_wh holds (w, h) of
- * every image of f (Shape2D, stitch/match_info.hh:53-78).
+ * every image of f (Shape2D, stitch/match_info.hh:53-78).  The matched point pairs are gathered on the
+ * device from m's resident lists and f's coordinates (nothing is re-uploaded); one D2H brings back the
+ * winners and the gathered points for the host-side acceptance gates of fill_inliers_to_matchinfo.
  * Homography (8-point samples) unless cfg->CYLINDER || cfg->TRANS (affine, 7-point samples).
  * Sampling is std::mt19937 with the reference's duplicate rejection; pair p is seeded with
  * seeds[p], or from base_seed and p when seeds == NULL (the reference seeds from
@@ -223,6 +233,8 @@ int op_ransac_inlier_count(const op_ransac_result* r, int p);
 int op_ransac_inliers(const op_ransac_result* r, int p, int* match_indices);
 /* index of the winning hypothesis and its inlier count (-1: no healthy hypothesis) */
 int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count);
+/* number of accepted pairs and the inliers they hold, over the whole result */
+int op_ransac_summary(const op_ransac_result* r, int* accepted_pairs, int64_t* inliers);
 void op_ransac_free(op_ransac_result* r);
 
 /* =====================================================================================

@@ -222,6 +222,7 @@ void op_ctx_destroy(op_ctx* c) {
 	hipSetDevice(c->device);
 	hipStreamSynchronize(c->stream);
 	op_ctx_release_workspace(c);
+	c->match_arena.release(); c->ransac_arena.release();
 	pool_trim();
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);

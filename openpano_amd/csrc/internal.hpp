@@ -30,6 +30,23 @@ struct op_ctx {
 	struct Pending { int stage; hipEvent_t a, b; };
 	std::vector<Pending> pending;                    // recorded, not yet resolved
 	void* pinned = nullptr; size_t pinned_cap = 0;   // grow-only pinned host scratch for D2H results
+	// grow-only device scratch of the matcher and of RANSAC: a call's temporaries live here, so kernels that are
+	// still queued when the call returns (the per-pair sort into the result buffer) keep valid inputs -- the next
+	// call on this context is ordered behind them on the same stream (contexts are thread-compatible)
+	struct DevScratch {
+		void* p = nullptr; size_t cap = 0;
+		hipError_t ensure(size_t bytes) {
+			if (bytes <= cap) return hipSuccess;
+			if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }   // hipFree waits for the device
+			const size_t want = bytes + bytes / 8;
+			hipError_t e = hipMalloc(&p, want);
+			if (e != hipSuccess) return e;
+			cap = want;
+			return hipSuccess;
+		}
+		void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+	};
+	DevScratch match_arena, ransac_arena;
 	void* pinned_scratch(size_t bytes) {
 		if (bytes <= pinned_cap) return pinned;
 		if (pinned) hipHostFree(pinned);

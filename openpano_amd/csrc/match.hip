@@ -21,28 +21,71 @@
 #include <cstring>
 #include <memory>
 #include <algorithm>
+#include <mutex>
 
 struct op_features;   // sift_host.hip
 struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
 FeatView op_features_view(const op_features* f);
 
+// The result of a match call stays in HBM: per image pair a (first, second) list sorted by (first, second),
+// pairs back to back in job order.  op_ransac_pairs reads it there; the host only learns the per-pair counts
+// with the call and fetches the index lists the first time somebody asks for them (op_matches_copy).
 struct op_matches {
 	int npairs = 0;
-	std::vector<std::vector<int>> pairs;   // per image pair: flat (first, second) sorted
+	std::vector<int> count;            // matches of pair p
+	std::vector<int64_t> offset;       // npairs + 1: first entry of pair p in the flat list
+	std::vector<int> lim;              // npairs x 2: keypoint counts of the two images the indices refer to (empty: unknown, lists came from the host)
 	int64_t total = 0;
+	int* d_idx = nullptr;              // device, total x (first, second); null when the lists only exist on the host
+	int device = -1; hipStream_t stream = nullptr;       // where d_idx was produced (its producer kernels are ordered on this stream)
+	mutable std::vector<int> h_idx;    // host mirror of d_idx, fetched on first use
+	mutable bool host_valid = false;
+	mutable std::mutex mu;
+	~op_matches() { if (d_idx) { hipSetDevice(device); pool_free(d_idx); } }
 };
 
-const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p) { return m->pairs[p]; }
 int op_matches_num_pairs(const op_matches* m) { return m->npairs; }
-// multi.hip: parts[k] holds the pairs index[k][0..] of the job's pair list -> one op_matches in job order
+const std::vector<int>& op_matches_counts(const op_matches* m) { return m->count; }
+const std::vector<int64_t>& op_matches_offsets(const op_matches* m) { return m->offset; }
+const std::vector<int>& op_matches_limits(const op_matches* m) { return m->lim; }
+// flat host list (total x 2), fetched from the device once; nullptr + error set on failure
+const int* op_matches_host(const op_matches* m) {
+	std::lock_guard<std::mutex> lk(m->mu);
+	if (m->host_valid) return m->h_idx.data();
+	m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
+	if (m->total && m->d_idx) {
+		hipError_t e = hipSetDevice(m->device);
+		if (e == hipSuccess) e = hipMemcpyAsync(m->h_idx.data(), m->d_idx, sizeof(int) * 2 * (size_t)m->total, hipMemcpyDeviceToHost, m->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+		if (e != hipSuccess) { op_set_error(std::string("op_matches: result copy failed: ") + hipGetErrorString(e)); return nullptr; }
+	}
+	m->host_valid = true;
+	return m->h_idx.data();
+}
+// device list on `device` if the matches live there (else nullptr: the caller uploads the host list)
+const int* op_matches_device(const op_matches* m, int device) { return (m->d_idx && m->device == device) ? m->d_idx : nullptr; }
+// multi.hip: parts[k] holds the pairs index[k][0..] of the job's pair list -> one op_matches in job order.
+// The parts live on different devices; the merged object is host-resident (RANSAC uploads what it needs).
 op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::vector<int>>& index, int npairs) {
 	op_matches* m = new op_matches;
-	m->npairs = npairs; m->pairs.resize(npairs);
+	m->npairs = npairs; m->count.assign(npairs, 0); m->offset.assign(npairs + 1, 0); m->lim.assign((size_t)npairs * 2, 0);
 	for (size_t k = 0; k < index.size(); ++k)
 		for (size_t q = 0; q < index[k].size(); ++q) {
-			m->pairs[index[k][q]] = std::move(parts[k]->pairs[q]);
-			m->total += (int64_t)(m->pairs[index[k][q]].size() / 2);
+			m->count[index[k][q]] = parts[k]->count[q];
+			if (!parts[k]->lim.empty()) { m->lim[2 * (size_t)index[k][q]] = parts[k]->lim[2 * q]; m->lim[2 * (size_t)index[k][q] + 1] = parts[k]->lim[2 * q + 1]; }
 		}
+	for (int p = 0; p < npairs; ++p) m->offset[p + 1] = m->offset[p] + m->count[p];
+	m->total = m->offset[npairs];
+	m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
+	for (size_t k = 0; k < index.size(); ++k) {
+		const int* src = op_matches_host(parts[k]);
+		if (!src) { delete m; return nullptr; }
+		for (size_t q = 0; q < index[k].size(); ++q) {
+			const int c = parts[k]->count[q];
+			if (c) std::memcpy(m->h_idx.data() + 2 * m->offset[index[k][q]], src + 2 * parts[k]->offset[q], sizeof(int) * 2 * (size_t)c);
+		}
+	}
+	m->host_valid = true;
 	return m;
 }
 
@@ -184,7 +227,9 @@ struct MatchState {
 	float* fnext;       // per A row: exact second-min distance
 	int* surv;          // per pair region (res_off .. res_off+ka): A rows that passed the first ratio test
 	int* nsurv;         // per pair
-	int* mlist;         // accepted matches: [0] = count, then (pair, a, b) triples in arrival order
+	int* mcount;        // accepted matches of the call ...
+	int* mtrip;         // ... as (pair, a, b) triples in arrival order
+	int* pcnt;          // ... and counted per pair
 	int* slow_fwd; int* slow_rev;   // rows needing a full scan: (pair, row) pairs ...
 	int* slow_sorted;   // ... and the queue being scanned, grouped by scanned image (k_slow_order)
 	int* slow_fwd_n; int* slow_rev_n;   // ... and their counts
@@ -206,9 +251,10 @@ __device__ __forceinline__ void finish_forward(const MatchState& S, const PairDe
 __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDesc& pd, int pair, int a, float next_min) {
 	const long long o = (long long)pd.res_off + a;
 	if (!(S.fmn[o] > S.rr * next_min)) {
-		const int slot = atomicAdd(&S.mlist[0], 1);        // a row is accepted at most once: slot < total rows
-		int* q = S.mlist + 1 + 3 * (long long)slot;
+		const int slot = atomicAdd(S.mcount, 1);           // a row is accepted at most once: slot < total rows
+		int* q = S.mtrip + 3 * (long long)slot;
 		q[0] = pair; q[1] = a; q[2] = S.fb[o];
+		atomicAdd(&S.pcnt[pair], 1);
 	}
 }
 
@@ -323,9 +369,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			const f32x4 v = *(const f32x4*)&s_nyh[buf][8 * g + 4 * h];
 			acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
 		}
-#if OP_MATCH_EXPERIMENT == 2      // timing experiment: no MFMA
-		for (int kb = 0; kb < 8; ++kb) { const uint4 q = yrow[2 * kb + h]; acc[kb] = __uint_as_float(q.x ^ xh[kb].x); acc[kb + 8] = __uint_as_float(q.y ^ xl[kb].y); }
-#else
 		// (raising the wave's priority over the chain, or splitting it over two accumulators, changes nothing:
 		// DESIGN.md section 6)
 #pragma unroll
@@ -336,7 +379,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
-#endif
 #if OP_MATCH_EXPERIMENT == 9
 		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
 #endif
@@ -345,11 +387,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		const float old_keys[NK] = {ts[0], ts[1], ts[2], ts[3]};
 #pragma unroll
 		for (int reg = 0; reg < 16; ++reg) {
-#if OP_MATCH_EXPERIMENT == 3      // timing experiment: scores are only folded into one value
-			ts[0] = fmaxf(ts[0], acc[reg]);
-#else
 			topk_keys(ts, score_key(acc[reg], reg));
-#endif
 		}
 		topk_attribute(old_keys, ts, ti, t);          // ti[] holds TILE numbers until the sweep ends
 		STAMP(2);
@@ -572,6 +610,73 @@ __global__ void __launch_bounds__(256) k_match_slow(MatchState S, int grouped) {
 	}
 }
 
+// ---- result lists on the device: (pair, a, b) triples in arrival order -> per pair <first, second> sorted ----
+// exclusive prefix of the per-pair counts (one workgroup; a job has thousands of pairs)
+__global__ void __launch_bounds__(1024) k_match_offsets(const int* __restrict__ pcnt, int npairs, int* __restrict__ poff) {
+	__shared__ int s_part[16];
+	__shared__ int s_carry;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (tid == 0) s_carry = 0;
+	__syncthreads();
+	for (int base = 0; base < npairs; base += 1024) {
+		const int i = base + tid;
+		const int v = i < npairs ? pcnt[i] : 0;
+		int incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+		if (lane == 63) s_part[wave] = incl;
+		__syncthreads();
+		int pre = s_carry;
+		for (int w = 0; w < wave; ++w) pre += s_part[w];
+		if (i < npairs) poff[i] = pre + incl - v;
+		__syncthreads();
+		if (tid == 1023) s_carry = pre + incl;
+		__syncthreads();
+	}
+	if (tid == 0) poff[npairs] = s_carry;
+}
+// every triple to an (unordered) slot of its pair's segment, in the reference's <first, second> form:
+// <b, a> when the pair was matched with its sets swapped (matcher.cc:68-69)
+__global__ void __launch_bounds__(256) k_match_place(MatchState S, const int* __restrict__ poff, int* __restrict__ fill, int2* __restrict__ seg) {
+	const int n = *S.mcount;
+	for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+		const int* q = S.mtrip + 3 * (long long)e;
+		const int pair = q[0];
+		const int slot = atomicAdd(&fill[pair], 1);
+		seg[poff[pair] + slot] = S.pairs[pair].rev ? make_int2(q[2], q[1]) : make_int2(q[1], q[2]);
+	}
+}
+// rank sort of every pair's segment by (first, second) -- arrival order on the device is arbitrary, the (a, b) of a
+// pair are distinct, so ranks are a permutation.  Workgroup per pair; segments up to kSortLds entries are ranked
+// from LDS, longer ones (thousands of matches in one image pair) straight from global memory.
+constexpr int kSortLds = 4096;
+__global__ void __launch_bounds__(256) k_match_sort(const int* __restrict__ pcnt, const int* __restrict__ poff, const int2* __restrict__ seg, int2* __restrict__ out) {
+	__shared__ unsigned long long s_key[kSortLds];
+	const int pair = blockIdx.x, m = pcnt[pair];
+	if (m == 0) return;
+	const int2* in = seg + poff[pair]; int2* o = out + poff[pair];
+	const int tid = threadIdx.x;
+	if (m == 1) { if (tid == 0) o[0] = in[0]; return; }
+	auto key_of = [](int2 v) { return ((unsigned long long)(unsigned)v.x << 32) | (unsigned)v.y; };
+	if (m <= kSortLds) {
+		for (int i = tid; i < m; i += 256) s_key[i] = key_of(in[i]);
+		__syncthreads();
+		for (int i = tid; i < m; i += 256) {
+			const unsigned long long k = s_key[i];
+			int r = 0;
+			for (int j = 0; j < m; ++j) r += s_key[j] < k ? 1 : 0;
+			o[r] = make_int2((int)(k >> 32), (int)(unsigned)k);
+		}
+	} else {
+		for (int i = tid; i < m; i += 256) {
+			const unsigned long long k = key_of(in[i]);
+			int r = 0;
+			for (int j = 0; j < m; ++j) r += key_of(in[j]) < k ? 1 : 0;
+			o[r] = make_int2((int)(k >> 32), (int)(unsigned)k);
+		}
+	}
+}
+
 }	// namespace
 
 extern "C" {
@@ -584,8 +689,9 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const long long total = fv.offsets[fv.n];
 	if (!fv.desc) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: features hold coordinates only (built without descriptors)");
 	op_matches* m = new op_matches;
-	m->npairs = npairs; m->pairs.resize(npairs);
-	if (npairs == 0 || total == 0) { *out = m; return OP_OK; }
+	m->npairs = npairs; m->count.assign(npairs, 0); m->offset.assign(npairs + 1, 0); m->lim.assign((size_t)npairs * 2, 0);
+	m->device = ctx->device; m->stream = ctx->stream;
+	if (npairs == 0 || total == 0) { m->host_valid = true; m->h_idx.resize(2); *out = m; return OP_OK; }
 
 	std::unique_ptr<HostScope> hs(new HostScope(ctx, "matcher work list + launches (host)"));
 	std::vector<WorkItem> work;
@@ -601,6 +707,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		pd.b_off = (int)fv.offsets[ib]; pd.kb = fv.counts[ib];
 		pd.rev = rev; pd.ia = ia; pd.ib = ib;
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
+		m->lim[2 * (size_t)p] = fv.counts[i]; m->lim[2 * (size_t)p + 1] = fv.counts[j];
 	}
 	{	// Workgroups are handed to the 8 XCDs round-robin by index.  The row blocks of one pair (which stream the
 		// same Y set) go to ONE XCD, back to back: Y then comes from HBM once and from that XCD's L2 for the other
@@ -629,18 +736,16 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t nres = (size_t)std::max<long long>(res_rows, 1);
 	const int slow_cap = (int)std::min<long long>(std::max<long long>(res_rows, 1), 1 << 22);
 
-	// One device arena, one memset, one upload per call (every runtime call costs microseconds and
-	// this function used to make about thirty).  Layout: a control block of counters that ends in
-	// the head of the accepted-match list -- so the zero-fill is one range and the result copy
-	// starts at the list's count -- followed by the per-call arrays.
-	// accepted matches come back as one packed list (count + triples); the first copy takes a
-	// head of kHead entries, which covers the usual few percent of rows, a second one the rest
-	const size_t kHead = std::min<size_t>(nres, 1 << 14);
+	// One device arena (the context's grow-only matcher scratch), one memset, one upload per call (every runtime
+	// call costs microseconds).  Layout: a control block of counters -- zero-filled as one range, its head
+	// [slow_fwd_n, slow_rev_n, match count, matches per pair] is what comes back to the host -- followed by
+	// the per-call arrays.
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-	const size_t n_ctrl = 3 + (size_t)npairs + 1;                      // gmax, slow_fwd_n, slow_rev_n, nsurv[npairs], mlist count
+	const size_t n_ctrl = 4 + 4 * (size_t)npairs + 1;                  // gmax, slow_fwd_n, slow_rev_n, mcount, pcnt[np], nsurv[np], fill[np], poff[np + 1]
 	const size_t o_ctrl = 0;
-	const size_t o_trip = sizeof(int) * n_ctrl;                        // triples follow the count directly
-	const size_t o_norms = al(o_trip + sizeof(int) * 3 * nres);
+	const size_t o_trip = al(sizeof(int) * n_ctrl);
+	const size_t o_seg = al(o_trip + sizeof(int) * 3 * nres);          // unsorted <first, second> segments
+	const size_t o_norms = al(o_seg + sizeof(int) * 2 * nres);
 	const size_t o_split = al(o_norms + sizeof(float) * total);
 	const size_t o_fmn = al(o_split + 512 * (size_t)total);
 	const size_t o_fnext = al(o_fmn + sizeof(float) * nres);
@@ -651,27 +756,27 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t up_bytes = sizeof(PairDesc) * npairs + sizeof(WorkItem) * work.size();
 	const size_t arena_bytes = o_up + al(up_bytes);
 	char* arena = nullptr;
-	const size_t hml_bytes = al(sizeof(int) * (1 + 3 * nres));
-	char* pin = (char*)ctx->pinned_scratch(hml_bytes + al(up_bytes) + 256);   // pinned: copies run at link rate, asynchronously
+	const size_t hres_bytes = al(sizeof(int) * (3 + (size_t)npairs));
+	char* pin = (char*)ctx->pinned_scratch(hres_bytes + al(up_bytes));          // pinned: copies run at link rate, asynchronously
 	int rc = OP_OK;
 	if (!pin) { delete m; OP_FAIL(OP_ERR_HIP, "op_match_pairs: pinned host allocation failed"); }
-	int* h_ml = (int*)pin;
-	int* h_slow = (int*)(pin + hml_bytes + al(up_bytes));                  // slow_fwd_n, slow_rev_n of this call
-	h_slow[0] = h_slow[1] = 0;
-	std::memcpy(pin + hml_bytes, pds.data(), sizeof(PairDesc) * npairs);
-	if (!work.empty()) std::memcpy(pin + hml_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
+	int* h_res = (int*)pin;                                                // slow_fwd_n, slow_rev_n, match count, matches per pair
+	h_res[0] = h_res[1] = h_res[2] = 0;
+	std::memcpy(pin + hres_bytes, pds.data(), sizeof(PairDesc) * npairs);
+	if (!work.empty()) std::memcpy(pin + hres_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
-	MCHK(pool_alloc((void**)&arena, arena_bytes));
+	MCHK(ctx->match_arena.ensure(arena_bytes));
+	arena = (char*)ctx->match_arena.p;
 	{
 		int* ctrl = (int*)(arena + o_ctrl);
-		int* d_mlist = ctrl + 3 + npairs;                              // [count][triples ...]
+		int* d_pcnt = ctrl + 4; int* d_fill = ctrl + 4 + 2 * (size_t)npairs; int* d_poff = ctrl + 4 + 3 * (size_t)npairs;
 		MCHK(hipMemsetAsync(ctrl, 0, sizeof(int) * n_ctrl, st));
-		MCHK(hipMemcpyAsync(arena + o_up, pin + hml_bytes, up_bytes, hipMemcpyHostToDevice, st));
+		MCHK(hipMemcpyAsync(arena + o_up, pin + hres_bytes, up_bytes, hipMemcpyHostToDevice, st));
 		MatchState S;
 		S.desc = fv.desc; S.split = (const uint4*)(arena + o_split); S.norms = (const float*)(arena + o_norms);
 		S.gmax_bits = (const unsigned*)ctrl; S.pairs = (const PairDesc*)(arena + o_up);
 		S.fb = (int*)(arena + o_fb); S.fmn = (float*)(arena + o_fmn); S.fnext = (float*)(arena + o_fnext);
-		S.surv = (int*)(arena + o_surv); S.nsurv = ctrl + 3; S.mlist = d_mlist;
+		S.surv = (int*)(arena + o_surv); S.nsurv = ctrl + 4 + npairs; S.mcount = ctrl + 3; S.mtrip = (int*)(arena + o_trip); S.pcnt = d_pcnt;
 		S.slow_fwd = (int*)(arena + o_slow); S.slow_rev = S.slow_fwd + 2 * (size_t)slow_cap; S.slow_sorted = S.slow_fwd + 4 * (size_t)slow_cap;
 		S.slow_fwd_n = ctrl + 1; S.slow_rev_n = ctrl + 2; S.slow_cap = slow_cap;
 		const int grouped = fv.n <= kOrderBins;                         // the grouping kernel keeps one LDS counter per image
@@ -701,63 +806,43 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 				hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(256), 0, st, S, grouped);
 				MCHK(hipGetLastError());
 			}
+			{
+				ProfScope ps(ctx, "matcher result lists");
+				hipLaunchKernelGGL(k_match_offsets, dim3(1), dim3(1024), 0, st, (const int*)d_pcnt, npairs, d_poff);
+				hipLaunchKernelGGL(k_match_place, dim3((unsigned)std::min<size_t>((nres + 255) / 256, 512)), dim3(256), 0, st, S, (const int*)d_poff, d_fill, (int2*)(arena + o_seg));
+				MCHK(hipGetLastError());
+			}
+			MCHK(hipMemcpyAsync(h_res, ctrl + 1, sizeof(int) * (3 + (size_t)npairs), hipMemcpyDeviceToHost, st));
 		}
-	}
-	int* d_mlist; d_mlist = (int*)(arena + o_ctrl) + 3 + npairs;
-	h_ml[0] = 0;
-	hs.reset(); hs.reset(new HostScope(ctx, "matcher wait + result copy (host)"));
-	if (!work.empty()) {
-		MCHK(hipMemcpyAsync(h_ml, d_mlist, sizeof(int) * (1 + 3 * kHead), hipMemcpyDeviceToHost, st));
-		MCHK(hipMemcpyAsync(h_slow, (int*)(arena + o_ctrl) + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+		hs.reset(); hs.reset(new HostScope(ctx, "matcher wait + counts (host)"));
 		MCHK(hipStreamSynchronize(st));
+		resolve_profile(ctx);                            // (the sort below stays pending until the next resolve: no second wait)
 #if OP_MATCH_EXPERIMENT == 9
-		fprintf(stderr, "[match trace] exact-scan rows: forward %d, reverse %d\n", h_slow[0], h_slow[1]);
+		fprintf(stderr, "[match trace] exact-scan rows: forward %d, reverse %d\n", h_res[0], h_res[1]);
 #endif
-		if (h_slow[0] > slow_cap || h_slow[1] > slow_cap) {
-			// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
-			// descriptors in one call): the rows beyond the queue were not matched -- never return that as OP_OK
-			op_set_error("op_match_pairs: exact-scan queue overflow (" + std::to_string(std::max(h_slow[0], h_slow[1])) + " rows > " +
-					std::to_string(slow_cap) + "); split the pair list");
-			rc = OP_ERR_CAPACITY; goto done;
-		}
-		if ((size_t)h_ml[0] > kHead) {
-			MCHK(hipMemcpyAsync(h_ml + 1 + 3 * kHead, d_mlist + 1 + 3 * kHead, sizeof(int) * 3 * ((size_t)h_ml[0] - kHead), hipMemcpyDeviceToHost, st));
-			MCHK(hipStreamSynchronize(st));
-		}
-	} else MCHK(hipStreamSynchronize(st));
-	resolve_profile(ctx);
-	hs.reset(); hs.reset(new HostScope(ctx, "matcher result lists (host)"));
-	{
-		// counting sort of the (pair, a, b) triples by pair into one flat array, then every pair's
-		// slice is put into the reference's <first, second> form and sorted (arrival order on the
-		// device is arbitrary) -- the per-pair part runs on the host pool
-		const int nm = h_ml[0];
-		std::vector<int> start(npairs + 1, 0);
-		for (int e = 0; e < nm; ++e) ++start[h_ml[1 + 3 * (size_t)e] + 1];
-		for (int p = 0; p < npairs; ++p) start[p + 1] += start[p];
-		std::vector<std::pair<int, int>> flat((size_t)nm);
-		{
-			std::vector<int> fill(start.begin(), start.end() - 1);
-			for (int e = 0; e < nm; ++e) {
-				const int* q = h_ml + 1 + 3 * (size_t)e;
-				flat[(size_t)fill[q[0]]++] = pds[q[0]].rev ? std::make_pair(q[2], q[1]) : std::make_pair(q[1], q[2]);   // <b, a> when swapped (matcher.cc:68-69)
+		if (!work.empty()) {
+			if (h_res[0] > slow_cap || h_res[1] > slow_cap) {
+				// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
+				// descriptors in one call): the rows beyond the queue were not matched -- never return that as OP_OK
+				op_set_error("op_match_pairs: exact-scan queue overflow (" + std::to_string(std::max(h_res[0], h_res[1])) + " rows > " +
+						std::to_string(slow_cap) + "); split the pair list");
+				rc = OP_ERR_CAPACITY; goto done;
+			}
+			for (int p = 0; p < npairs; ++p) { m->count[p] = h_res[3 + p]; m->offset[p + 1] = m->offset[p] + h_res[3 + p]; }
+			m->total = m->offset[npairs];
+			if (m->total != h_res[2]) { op_set_error("op_match_pairs: per-pair counts do not add up to the match count"); rc = OP_ERR_HIP; goto done; }
+			if (m->total) {
+				// the sorted lists go straight into the result buffer (exact size, known now); the kernel reads the
+				// context's arena, which stays valid: whatever uses this context next is ordered behind it
+				MCHK(pool_alloc((void**)&m->d_idx, sizeof(int) * 2 * (size_t)m->total));
+				ProfScope ps(ctx, "matcher result lists");
+				hipLaunchKernelGGL(k_match_sort, dim3((unsigned)npairs), dim3(256), 0, st, (const int*)d_pcnt, (const int*)d_poff, (const int2*)(arena + o_seg), (int2*)m->d_idx);
+				MCHK(hipGetLastError());
 			}
 		}
-		const int chunk = 32, nchunks = (npairs + chunk - 1) / chunk;
-		host_parallel_for(nchunks, [&](int c) {
-			for (int p = c * chunk; p < std::min(npairs, (c + 1) * chunk); ++p) {
-				std::pair<int, int>* b0 = flat.data() + start[p]; std::pair<int, int>* b1 = flat.data() + start[p + 1];
-				if (b1 - b0 > 1) std::sort(b0, b1);
-				std::vector<int>& v = m->pairs[p];
-				v.resize(2 * (size_t)(b1 - b0));
-				for (std::pair<int, int>* it = b0; it != b1; ++it) { v[2 * (it - b0)] = it->first; v[2 * (it - b0) + 1] = it->second; }
-			}
-		});
-		m->total = nm;
 	}
 done:
 	hs.reset();
-	pool_free(arena);
 #undef MCHK
 	if (rc != OP_OK) { delete m; return rc; }
 	*out = m;
@@ -781,22 +866,39 @@ int op_debug_match_occupancy(unsigned long long* out) {
 int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out) {
 	if (!idx_pairs || !counts || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_matches_from_host: bad argument");
 	op_matches* m = new op_matches;
-	m->npairs = npairs; m->pairs.resize(npairs);
+	m->npairs = npairs; m->count.assign(npairs, 0); m->offset.assign(npairs + 1, 0);
 	for (int p = 0; p < npairs; ++p) {
 		if (counts[p] < 0) { delete m; OP_FAIL(OP_ERR_INVALID, "negative count"); }
-		m->pairs[p].assign(idx_pairs[p], idx_pairs[p] + 2 * (size_t)counts[p]);
-		m->total += counts[p];
+		m->count[p] = counts[p]; m->offset[p + 1] = m->offset[p] + counts[p];
 	}
+	m->total = m->offset[npairs];
+	m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
+	for (int p = 0; p < npairs; ++p)
+		if (counts[p]) std::memcpy(m->h_idx.data() + 2 * m->offset[p], idx_pairs[p], sizeof(int) * 2 * (size_t)counts[p]);
+	m->host_valid = true;
 	*out = m;
 	return OP_OK;
 }
 
-int op_matches_count(const op_matches* m, int p) { return (m && p >= 0 && p < m->npairs) ? (int)(m->pairs[p].size() / 2) : 0; }
+int op_matches_count(const op_matches* m, int p) { return (m && p >= 0 && p < m->npairs) ? m->count[p] : 0; }
 int op_matches_copy(const op_matches* m, int p, int* idx_pairs) {
 	if (!m || p < 0 || p >= m->npairs || !idx_pairs) OP_FAIL(OP_ERR_INVALID, "op_matches_copy: bad argument");
-	std::copy(m->pairs[p].begin(), m->pairs[p].end(), idx_pairs);
+	const int* h = op_matches_host(m);
+	if (!h) return OP_ERR_HIP;
+	if (m->count[p]) std::memcpy(idx_pairs, h + 2 * m->offset[p], sizeof(int) * 2 * (size_t)m->count[p]);
 	return OP_OK;
 }
+int op_matches_copy_all(const op_matches* m, int* idx_pairs, int64_t* offsets) {
+	if (!m) OP_FAIL(OP_ERR_INVALID, "op_matches_copy_all: bad argument");
+	if (offsets) std::copy(m->offset.begin(), m->offset.end(), offsets);
+	if (idx_pairs && m->total) {
+		const int* h = op_matches_host(m);
+		if (!h) return OP_ERR_HIP;
+		std::memcpy(idx_pairs, h, sizeof(int) * 2 * (size_t)m->total);
+	}
+	return OP_OK;
+}
+const int* op_matches_device_list(const op_matches* m) { return m ? m->d_idx : nullptr; }
 int64_t op_matches_total(const op_matches* m) { return m ? m->total : 0; }
 void op_matches_free(op_matches* m) { delete m; }
 

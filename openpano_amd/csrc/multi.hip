@@ -118,7 +118,7 @@ int op_match_pairs_multi(op_group* g, const op_config* cfg, const op_features* f
 	for (auto& t : th) t.join();
 	int rc = OP_OK;
 	for (int k = 0; k < nd; ++k) if (rcs[k] != OP_OK && rc == OP_OK) { rc = rcs[k]; op_set_error("device shard " + std::to_string(k) + ": " + errs[k]); }
-	if (rc == OP_OK) *out = op_matches_merge(parts.data(), mine, npairs);
+	if (rc == OP_OK) { *out = op_matches_merge(parts.data(), mine, npairs); if (!*out) rc = OP_ERR_HIP; }
 	for (op_matches* m : parts) op_matches_free(m);
 	for (op_features* r : replica) op_features_free(r);
 	return rc;

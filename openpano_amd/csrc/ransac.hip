@@ -27,9 +27,14 @@ struct op_features;
 struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
 FeatView op_features_view(const op_features* f);
 const double* op_features_coor_device(const op_features* f);
+const double* op_features_coor_host(const op_features* f, op_ctx* ctx);
 struct op_matches;
-const std::vector<int>& op_matches_pair_vector(const op_matches* m, int p);
 int op_matches_num_pairs(const op_matches* m);
+const std::vector<int>& op_matches_counts(const op_matches* m);
+const std::vector<int64_t>& op_matches_offsets(const op_matches* m);
+const std::vector<int>& op_matches_limits(const op_matches* m);
+const int* op_matches_host(const op_matches* m);
+const int* op_matches_device(const op_matches* m, int device);
 
 using opransac::P2;
 
@@ -44,11 +49,29 @@ struct op_ransac_result {
 
 namespace {
 
-struct PairArgs { int pts_off, m, affine, nsample; double inlier_dist; long long samp_off; };
+struct PairArgs {
+	int pts_off, m, affine, nsample; double inlier_dist; long long samp_off;
+	long long moff;          // first entry of the pair's <first, second> list in the job's match list
+	int off_i, off_j;        // first keypoint of image i / image j in the feature table
+};
 
 constexpr int RANSAC_PTS_CHUNK = 512;
 
-// grid (ceil(iters/256), npairs)
+// The matched point pairs of every live image pair, gathered where both inputs already are: the match lists
+// op_match_pairs left in HBM and the keypoint coordinates of op_features (TransformEstimation's constructor
+// arguments, transform_estimate.cc:26-33: match.data[k] -> kp1[first], kp2[second]).  grid (ceil(max m / 256), live pairs)
+__global__ void __launch_bounds__(256) k_ransac_gather(const PairArgs* __restrict__ pairs, const int* __restrict__ active,
+		const int2* __restrict__ midx, const double2* __restrict__ coor, double* __restrict__ pts) {
+	const PairArgs pa = pairs[active[blockIdx.y]];
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= pa.m) return;
+	const int2 ab = midx[pa.moff + k];
+	const double2 p1 = coor[pa.off_i + ab.x], p2 = coor[pa.off_j + ab.y];
+	double2* o = (double2*)(pts + ((long long)pa.pts_off + k) * 4);
+	o[0] = p1; o[1] = p2;
+}
+
+// grid (ceil(iters/256), live pairs)
 __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__ pairs, const double* __restrict__ pts /* m x {p1x,p1y,p2x,p2y} */,
 		const unsigned short* __restrict__ samples, int iters, int* __restrict__ counts /* npairs x iters */, const int* __restrict__ active) {
 	__shared__ double s_pts[RANSAC_PTS_CHUNK * 4];
@@ -78,7 +101,7 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 			for (int i = 0; i < cn; ++i)
 				cnt += opransac::is_inlier(H, P2{s_pts[4 * i], s_pts[4 * i + 1]}, P2{s_pts[4 * i + 2], s_pts[4 * i + 3]}, pa.inlier_dist) ? 1 : 0;
 	}
-	if (hyp < iters) counts[(long long)pair * iters + hyp] = ok ? cnt : -1;
+	if (hyp < iters) counts[(long long)blockIdx.y * iters + hyp] = ok ? cnt : -1;      // per LIVE pair (slot blockIdx.y)
 }
 
 // Sample tables: the std::mt19937 draw sequence of TransformEstimation::get_transform with its
@@ -359,7 +382,7 @@ __global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ cou
 		const PairArgs* __restrict__ pairs, const unsigned short* __restrict__ samples, unsigned short* __restrict__ best_samp, const int* __restrict__ active) {
 	__shared__ int s_cnt[256], s_idx[256];
 	const int pair = active[blockIdx.x];
-	const int* c = counts + (long long)pair * iters;
+	const int* c = counts + (long long)blockIdx.x * iters;
 	int bc = -1, bi = -1;
 	for (int i = threadIdx.x; i < iters; i += 256) { const int v = c[i]; if (v > bc) { bc = v; bi = i; } }
 	s_cnt[threadIdx.x] = bc; s_idx[threadIdx.x] = bi;
@@ -371,10 +394,10 @@ __global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ cou
 		}
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) best[pair] = make_int2(s_idx[0], s_cnt[0]);
+	if (threadIdx.x == 0) best[blockIdx.x] = make_int2(s_idx[0], s_cnt[0]);          // results are stored per live slot
 	if (threadIdx.x < 8) {     // the winner's sample, for the host epilogue
 		const int bi0 = s_idx[0];
-		best_samp[pair * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[pair].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
+		best_samp[blockIdx.x * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[pair].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
 	}
 }
 
@@ -494,12 +517,12 @@ std::vector<P2> overlap_region(const Shape& shape1, const Shape& shape2, const d
 }
 
 struct PairHost {
-	int i, j, m;
-	const int* match;              // m x (first, second)
+	int i, j, m, slot;             // slot: index among the live pairs (-1: below the match-count gate)
 	const double* kp1; int nk1;    // image i keypoints (x, y) centred
 	const double* kp2; int nk2;
 	Shape s1, s2;
-	std::vector<double> pts;       // m x 4
+	const double* pts;             // m x 4 (p1x, p1y, p2x, p2y), gathered on the device
+	double inlier_dist;
 };
 
 }	// namespace
@@ -513,127 +536,163 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
 	const FeatView fv = op_features_view(f);
-	const long long total = fv.offsets[fv.n];
-	op_ransac_result* R = new op_ransac_result;
+	if (fv.device != ctx->device) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: the features live on another device than the context");
+	std::unique_ptr<op_ransac_result> R(new op_ransac_result);
 	R->items.resize(npairs);
-	if (npairs == 0) { *out = R; return OP_OK; }
-	if (op_matches_num_pairs(mt) != npairs) { delete R; OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: op_matches holds a different number of pairs than the pair list"); }
+	if (npairs == 0) { *out = R.release(); return OP_OK; }
+	if (op_matches_num_pairs(mt) != npairs) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: op_matches holds a different number of pairs than the pair list");
 	const bool affine = cfg->CYLINDER || cfg->TRANS;                    // transform_estimate.cc:34-37
 	const int nsample = (affine ? 6 : 8) / 2 + 4;                       // :53
 	const int iters = cfg->RANSAC_ITERATIONS;
-	if (iters <= 0 || iters > 65536) { delete R; OP_FAIL(OP_ERR_UNSUPPORTED, "RANSAC_ITERATIONS must be in [1, 65536]"); }
+	if (iters <= 0 || iters > 65536) OP_FAIL(OP_ERR_UNSUPPORTED, "RANSAC_ITERATIONS must be in [1, 65536]");
 
 	std::unique_ptr<HostScope> hs(new HostScope(ctx, "ransac upload + launch (host)"));
-	std::vector<double> coor((size_t)std::max<long long>(total, 1) * 2);
-	if (total) HIPCHK(hipMemcpyAsync(coor.data(), op_features_coor_device(f), sizeof(double) * 2 * total, hipMemcpyDeviceToHost, st));
-	HIPCHK(hipStreamSynchronize(st));
+	const std::vector<int>& mcount = op_matches_counts(mt);
+	const std::vector<int64_t>& moffset = op_matches_offsets(mt);
+	const std::vector<int>& mlim = op_matches_limits(mt);
+	const long long mtotal = moffset[npairs];
+	// The match lists index keypoints of f.  Lists made by op_match_pairs carry the keypoint counts they were made
+	// for; lists wrapped from host arrays (op_matches_from_host) are checked entry by entry: an index outside its
+	// image would be a read out of bounds on the device and in the epilogue below.
+	const int* h_lists = mlim.empty() ? op_matches_host(mt) : nullptr;
+	if (mlim.empty() && !h_lists) return OP_ERR_HIP;
 
-	// pass 1: what the sampling kernel needs (match counts, sample geometry) -- no coordinates yet
+	// pass 1: what the kernels need per pair -- counts and offsets only, no coordinates, no lists
 	std::vector<PairHost> ph(npairs);
-	std::vector<PairArgs> pa(npairs);
-	long long pts_total = 0;
+	std::vector<int> h_active;
+	long long pts_total = 0; int max_m = 0;
 	for (int p = 0; p < npairs; ++p) {
 		const int i = pairs[2 * p], j = pairs[2 * p + 1];
-		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) { delete R; OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: image index out of range"); }
-		const std::vector<int>& mv = op_matches_pair_vector(mt, p);
+		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: image index out of range");
 		PairHost& h = ph[p];
-		h.i = i; h.j = j; h.m = (int)(mv.size() / 2); h.match = mv.data();
-		h.kp1 = coor.data() + fv.offsets[i] * 2; h.nk1 = fv.counts[i];
-		h.kp2 = coor.data() + fv.offsets[j] * 2; h.nk2 = fv.counts[j];
+		h.i = i; h.j = j; h.m = mcount[p]; h.slot = -1; h.pts = nullptr;
+		h.nk1 = fv.counts[i]; h.nk2 = fv.counts[j];
 		h.s1 = Shape{shapes_wh[2 * i], shapes_wh[2 * i + 1]}; h.s2 = Shape{shapes_wh[2 * j], shapes_wh[2 * j + 1]};
-		if (h.m > 65535) { delete R; OP_FAIL(OP_ERR_CAPACITY, "more than 65535 matches in one pair"); }
-		// the match lists may come from the public op_matches_from_host or from another op_features:
-		// an index outside the image's keypoints would be a host heap read out of bounds below
-		for (int k = 0; k < h.m; ++k)
-			if ((unsigned)h.match[2 * k] >= (unsigned)h.nk1 || (unsigned)h.match[2 * k + 1] >= (unsigned)h.nk2) {
-				delete R;
-				OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: pair " + std::to_string(p) + " match " + std::to_string(k) + " indexes a keypoint outside its image");
-			}
+		if (h.m > 65535) OP_FAIL(OP_ERR_CAPACITY, "more than 65535 matches in one pair");
+		if (!mlim.empty()) {
+			if (mlim[2 * (size_t)p] > h.nk1 || mlim[2 * (size_t)p + 1] > h.nk2)
+				OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: pair " + std::to_string(p) + " was matched on images with more keypoints than f holds for it");
+		} else {
+			const int* q = h_lists + 2 * moffset[p];
+			for (int k = 0; k < h.m; ++k)
+				if ((unsigned)q[2 * k] >= (unsigned)h.nk1 || (unsigned)q[2 * k + 1] >= (unsigned)h.nk2)
+					OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: pair " + std::to_string(p) + " match " + std::to_string(k) + " indexes a keypoint outside its image");
+		}
 		// ransac_inlier_thres (float) and INLIER_DIST = sqr(float) (transform_estimate.cc:46,133)
 		const float thres = (float)((h.s1.w + h.s1.h) * 0.5 / 800 * cfg->RANSAC_INLIER_THRES);
-		const float inlier_dist = thres * thres;
-		pa[p] = PairArgs{(int)pts_total, h.m, affine ? 1 : 0, nsample, (double)inlier_dist, (long long)p * iters * 8};
-		pts_total += h.m;
+		h.inlier_dist = (double)(thres * thres);
+		if (h.m >= 8 && h.m >= nsample) {                                  // ESTIMATE_MIN_NR_MATCH (:21,39) / :55: otherwise get_transform -> false
+			h.slot = (int)h_active.size(); h_active.push_back(p); pts_total += h.m; max_m = std::max(max_m, h.m);
+		}
 	}
-	std::vector<int> h_active;
-	for (int p = 0; p < npairs; ++p) if (ph[p].m >= 8 && ph[p].m >= nsample) h_active.push_back(p);
 	const int nactive = (int)h_active.size();
-	// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
-	std::vector<unsigned> h_seeds(npairs);
-	for (int p = 0; p < npairs; ++p) h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
-	std::vector<double> pts_flat((size_t)std::max<long long>(pts_total, 1) * 4);
+	if (nactive == 0) { *out = R.release(); return OP_OK; }
 
-	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
-	PairArgs* d_pa = nullptr; double* d_pts = nullptr; unsigned short* d_samp = nullptr; int* d_counts = nullptr; int2* d_best = nullptr;
-	unsigned* d_seeds = nullptr; unsigned* d_state = nullptr; unsigned short* d_bsamp = nullptr; int* d_active = nullptr;
-	std::vector<int2> best(npairs);
-	std::vector<unsigned short> best_samp((size_t)npairs * 8);
+	// One device arena (the context's grow-only RANSAC scratch) and one pinned block: [PairArgs | seeds | live list |
+	// the match lists if they only exist on the host] go up in one copy, [winner | its sample | gathered points] come
+	// back in one copy.  Samples, generator states and hypothesis counts exist per LIVE pair only.
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const int* d_midx_resident = op_matches_device(mt, ctx->device);
+	const bool upload_lists = !d_midx_resident && mtotal > 0;
+	const size_t u_pa = 0, u_seeds = al(u_pa + sizeof(PairArgs) * npairs), u_active = al(u_seeds + sizeof(unsigned) * npairs),
+			u_lists = al(u_active + sizeof(int) * nactive), up_bytes = al(u_lists + (upload_lists ? sizeof(int) * 2 * (size_t)mtotal : 0));
+	const size_t r_best = 0, r_bsamp = al(r_best + sizeof(int2) * nactive), r_pts = al(r_bsamp + sizeof(unsigned short) * 8 * nactive),
+			down_bytes = al(r_pts + sizeof(double) * 4 * (size_t)pts_total);
+	const size_t o_up = 0, o_down = al(o_up + up_bytes), o_samp = al(o_down + down_bytes),
+			o_state = al(o_samp + sizeof(unsigned short) * 8 * (size_t)nactive * iters),
+			o_counts = al(o_state + sizeof(unsigned) * 624 * (size_t)nactive),
+			arena_bytes = al(o_counts + sizeof(int) * (size_t)nactive * iters);
+	char* pin = (char*)ctx->pinned_scratch(up_bytes + down_bytes);
+	if (!pin) OP_FAIL(OP_ERR_HIP, "op_ransac_pairs: pinned host allocation failed");
+	{
+		PairArgs* pa = (PairArgs*)(pin + u_pa);
+		unsigned* h_seeds = (unsigned*)(pin + u_seeds);
+		long long pts_off = 0;
+		for (int p = 0; p < npairs; ++p) {
+			const PairHost& h = ph[p];
+			pa[p] = PairArgs{(int)pts_off, h.m, affine ? 1 : 0, nsample, h.inlier_dist, (long long)std::max(h.slot, 0) * iters * 8,
+					(long long)moffset[p], (int)fv.offsets[h.i], (int)fv.offsets[h.j]};
+			if (h.slot >= 0) pts_off += h.m;
+			// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
+			h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
+		}
+		std::memcpy(pin + u_active, h_active.data(), sizeof(int) * nactive);
+		if (upload_lists) {
+			const int* hl = op_matches_host(mt);
+			if (!hl) return OP_ERR_HIP;
+			std::memcpy(pin + u_lists, hl, sizeof(int) * 2 * (size_t)mtotal);
+		}
+	}
+	const char* down = pin + up_bytes;
+	const int2* best = (const int2*)(down + r_best);
+	const unsigned short* best_samp = (const unsigned short*)(down + r_bsamp);
+	const double* coor_host = nullptr;
 	int rc = OP_OK;
 #define RCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
-	RCHK(pool_alloc((void**)&d_pa, sizeof(PairArgs) * npairs));
-	RCHK(pool_alloc((void**)&d_pts, sizeof(double) * pts_flat.size()));
-	RCHK(pool_alloc((void**)&d_samp, sizeof(unsigned short) * (size_t)npairs * iters * 8));
-	RCHK(pool_alloc((void**)&d_seeds, sizeof(unsigned) * npairs));
-	RCHK(pool_alloc((void**)&d_active, sizeof(int) * npairs));
-	RCHK(pool_alloc((void**)&d_state, sizeof(unsigned) * 624 * (size_t)npairs));
-	RCHK(pool_alloc((void**)&d_bsamp, sizeof(unsigned short) * 8 * npairs));
-	RCHK(pool_alloc((void**)&d_counts, sizeof(int) * (size_t)npairs * iters));
-	RCHK(pool_alloc((void**)&d_best, sizeof(int2) * npairs));
-	RCHK(hipMemcpyAsync(d_seeds, h_seeds.data(), sizeof(unsigned) * npairs, hipMemcpyHostToDevice, st));
-	RCHK(hipMemcpyAsync(d_pa, pa.data(), sizeof(PairArgs) * npairs, hipMemcpyHostToDevice, st));
-	{ ProfScope ps2(ctx, "ransac mt19937 samples");
-	  // pairs below the match-count gate (:21,39,55) never get a workgroup: launching 1024-thread groups that
-	  // exit at once costs more dispatcher time than the live ones compute (703 pairs, ~1/6 live on config 4)
-	  RCHK(hipMemsetAsync(d_best, 0xFF, sizeof(int2) * npairs, st));
-	  RCHK(hipMemsetAsync(d_bsamp, 0, sizeof(unsigned short) * 8 * npairs, st));
-	  if (nactive) {
-	    RCHK(hipMemcpyAsync(d_active, h_active.data(), sizeof(int) * nactive, hipMemcpyHostToDevice, st));
-	    hipLaunchKernelGGL(k_ransac_seed, dim3((nactive + 63) / 64), dim3(64), 0, st, d_seeds, d_active, nactive, d_state);
-	    RCHK(hipGetLastError());
-	    hipLaunchKernelGGL(k_ransac_samples, dim3(nactive), dim3(RS_T), 0, st, d_pa, d_state, iters, d_samp, d_active);
-	  }
-	  RCHK(hipGetLastError()); }
-	// pass 2, overlapped with the (latency-bound) sampling kernel: gather the matched point pairs
-	hs.reset(); hs.reset(new HostScope(ctx, "ransac gather points (host)"));
-	host_parallel_for(npairs, [&](int p) {
-		PairHost& h = ph[p];
-		h.pts.resize((size_t)h.m * 4);
-		for (int k = 0; k < h.m; ++k) {
-			const int a = h.match[2 * k], b = h.match[2 * k + 1];
-			h.pts[4 * k] = h.kp1[2 * a]; h.pts[4 * k + 1] = h.kp1[2 * a + 1];
-			h.pts[4 * k + 2] = h.kp2[2 * b]; h.pts[4 * k + 3] = h.kp2[2 * b + 1];
-		}
-		if (h.m) std::memcpy(pts_flat.data() + (size_t)pa[p].pts_off * 4, h.pts.data(), sizeof(double) * 4 * h.m);
-	});
-	hs.reset(); hs.reset(new HostScope(ctx, "ransac upload + launch (host)"));
-	RCHK(hipMemcpyAsync(d_pts, pts_flat.data(), sizeof(double) * pts_flat.size(), hipMemcpyHostToDevice, st));
 	{
-		ProfScope ps(ctx, "ransac hypotheses");
-		if (nactive) {
-		hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, nactive), dim3(256), 0, st, d_pa, d_pts, d_samp, iters, d_counts, d_active);
-		RCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_ransac_best, dim3(nactive), dim3(256), 0, st, d_counts, iters, d_best, d_pa, d_samp, d_bsamp, d_active);
+		RCHK(ctx->ransac_arena.ensure(arena_bytes));
+		char* arena = (char*)ctx->ransac_arena.p;
+		const PairArgs* d_pa = (const PairArgs*)(arena + o_up + u_pa);
+		const unsigned* d_seeds = (const unsigned*)(arena + o_up + u_seeds);
+		const int* d_active = (const int*)(arena + o_up + u_active);
+		const int2* d_midx = upload_lists ? (const int2*)(arena + o_up + u_lists) : (const int2*)d_midx_resident;
+		int2* d_best = (int2*)(arena + o_down + r_best);
+		unsigned short* d_bsamp = (unsigned short*)(arena + o_down + r_bsamp);
+		double* d_pts = (double*)(arena + o_down + r_pts);
+		unsigned short* d_samp = (unsigned short*)(arena + o_samp);
+		unsigned* d_state = (unsigned*)(arena + o_state);
+		int* d_counts = (int*)(arena + o_counts);
+		RCHK(hipMemcpyAsync(arena + o_up, pin, up_bytes, hipMemcpyHostToDevice, st));
+		{
+			ProfScope ps2(ctx, "ransac mt19937 samples");
+			// pairs below the match-count gate never get a workgroup: launching groups that exit at once costs more
+			// dispatcher time than the live ones compute (config 4: 703 pairs, ~640 live)
+			hipLaunchKernelGGL(k_ransac_seed, dim3((nactive + 63) / 64), dim3(64), 0, st, d_seeds, d_active, nactive, d_state);
+			RCHK(hipGetLastError());
+			hipLaunchKernelGGL(k_ransac_samples, dim3(nactive), dim3(RS_T), 0, st, d_pa, (const unsigned*)d_state, iters, d_samp, d_active);
+			RCHK(hipGetLastError());
 		}
-		RCHK(hipGetLastError());
+		{
+			ProfScope ps(ctx, "ransac hypotheses");
+			hipLaunchKernelGGL(k_ransac_gather, dim3((max_m + 255) / 256, nactive), dim3(256), 0, st, d_pa, d_active, d_midx,
+					(const double2*)op_features_coor_device(f), d_pts);
+			RCHK(hipGetLastError());
+			hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, nactive), dim3(256), 0, st, d_pa, (const double*)d_pts, (const unsigned short*)d_samp, iters, d_counts, d_active);
+			RCHK(hipGetLastError());
+			hipLaunchKernelGGL(k_ransac_best, dim3(nactive), dim3(256), 0, st, (const int*)d_counts, iters, d_best, d_pa, (const unsigned short*)d_samp, d_bsamp, d_active);
+			RCHK(hipGetLastError());
+		}
+		RCHK(hipMemcpyAsync(pin + up_bytes, arena + o_down, down_bytes, hipMemcpyDeviceToHost, st));
+		// the acceptance gates count the keypoints of both images inside the overlap polygon (:191-199): every
+		// coordinate of the job, fetched once per op_features (the first call waits for it; later ones find it)
+		coor_host = op_features_coor_host(f, ctx);
+		if (!coor_host) { rc = OP_ERR_HIP; goto done; }
+		RCHK(hipStreamSynchronize(st));
 	}
-	RCHK(hipMemcpyAsync(best.data(), d_best, sizeof(int2) * npairs, hipMemcpyDeviceToHost, st));
-	RCHK(hipMemcpyAsync(best_samp.data(), d_bsamp, sizeof(unsigned short) * 8 * npairs, hipMemcpyDeviceToHost, st));
-	RCHK(hipStreamSynchronize(st));
 	resolve_profile(ctx);
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac acceptance epilogue (host)"));
+	{
+		const PairArgs* pa = (const PairArgs*)(pin + u_pa);
+		for (int p = 0; p < npairs; ++p) {
+			PairHost& h = ph[p];
+			h.kp1 = coor_host + fv.offsets[h.i] * 2; h.kp2 = coor_host + fv.offsets[h.j] * 2;
+			if (h.slot >= 0) h.pts = (const double*)(down + r_pts) + (size_t)pa[p].pts_off * 4;
+		}
+	}
 
 	// ---- host epilogue per pair (transform_estimate.cc:85-86, 150-218) ----
 	host_parallel_for(npairs, [&](int p) {
 		op_ransac_result::Item& it = R->items[p];
 		const PairHost& h = ph[p];
-		it.best_hyp = best[p].x; it.best_count = best[p].y;
-		if (h.m < 8 || h.m < nsample || best[p].x < 0 || best[p].y < 0) return;     // get_transform -> false
-		const unsigned short* sp = best_samp.data() + (size_t)p * 8;
-		const double* P = h.pts.data();
+		if (h.slot < 0) return;                                                       // get_transform -> false (:55)
+		it.best_hyp = best[h.slot].x; it.best_count = best[h.slot].y;
+		if (it.best_hyp < 0 || it.best_count < 0) return;
+		const unsigned short* sp = best_samp + (size_t)h.slot * 8;
+		const double* P = h.pts;
 		double Hb[9];
 		opransac::calc_transform(nsample, [&](int q) { return P2{P[4 * sp[q]], P[4 * sp[q] + 1]}; },
 				[&](int q) { return P2{P[4 * sp[q] + 2], P[4 * sp[q] + 3]}; }, affine, Hb);
-		const double inlier_dist = pa[p].inlier_dist;
+		const double inlier_dist = h.inlier_dist;
 		std::vector<int> inl;
 		for (int k = 0; k < h.m; ++k)
 			if (opransac::is_inlier(Hb, P2{P[4 * k], P[4 * k + 1]}, P2{P[4 * k + 2], P[4 * k + 3]}, inlier_dist)) inl.push_back(k);
@@ -681,10 +740,9 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	});
 done:
 	hs.reset();
-	pool_free(d_pa); pool_free(d_pts); pool_free(d_samp); pool_free(d_counts); pool_free(d_best); pool_free(d_seeds); pool_free(d_state); pool_free(d_active); pool_free(d_bsamp);
 #undef RCHK
-	if (rc != OP_OK) { delete R; return rc; }
-	*out = R;
+	if (rc != OP_OK) return rc;
+	*out = R.release();
 	return OP_OK;
 }
 
@@ -702,6 +760,13 @@ int op_ransac_inliers(const op_ransac_result* r, int p, int* match_indices) {
 int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count) {
 	if (!r || p < 0 || p >= (int)r->items.size()) OP_FAIL(OP_ERR_INVALID, "op_ransac_best: bad argument");
 	if (hyp) *hyp = r->items[p].best_hyp; if (count) *count = r->items[p].best_count; return OP_OK;
+}
+int op_ransac_summary(const op_ransac_result* r, int* accepted_pairs, int64_t* inliers) {
+	if (!r) OP_FAIL(OP_ERR_INVALID, "op_ransac_summary: bad argument");
+	int ok = 0; int64_t inl = 0;
+	for (auto& it : r->items) if (it.ok) { ++ok; inl += (int64_t)it.inliers.size(); }
+	if (accepted_pairs) *accepted_pairs = ok; if (inliers) *inliers = inl;
+	return OP_OK;
 }
 void op_ransac_free(op_ransac_result* r) { delete r; }
 

@@ -76,11 +76,29 @@ struct op_features {
 	double* real = nullptr;            // device, total x 2 (real_coor in [0,1)); null when built from host/device arrays
 	bool has_desc = true;              // false: coordinates only (RANSAC-only use)
 	int device = 0;
+	// host mirror of coor, fetched the first time a host stage asks for it (the acceptance epilogue of
+	// op_ransac_pairs walks every keypoint of both images; features are immutable, so one copy serves every call)
+	mutable std::vector<double> h_coor; mutable bool h_coor_valid = false; mutable std::mutex h_mu;
 };
 
 struct FeatView { int n; const int* counts; const int64_t* offsets; const float* desc; int device; };
 FeatView op_features_view(const op_features* f) {
 	return FeatView{f->n, f->counts.data(), f->offsets.data(), f->has_desc ? f->desc : nullptr, f->device};
+}
+
+// total x 2 centred coordinates on the host (nullptr + error set on failure); ordered on ctx's stream
+const double* op_features_coor_host(const op_features* f, op_ctx* ctx) {
+	std::lock_guard<std::mutex> lk(f->h_mu);
+	if (f->h_coor_valid) return f->h_coor.data();
+	const int64_t total = f->offsets[f->n];
+	f->h_coor.resize((size_t)std::max<int64_t>(total, 1) * 2);
+	if (total) {
+		hipError_t e = hipMemcpyAsync(f->h_coor.data(), f->coor, sizeof(double) * 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) { op_set_error(std::string("op_features: coordinate copy failed: ") + hipGetErrorString(e)); return nullptr; }
+	}
+	f->h_coor_valid = true;
+	return f->h_coor.data();
 }
 
 struct op_sift_dump {

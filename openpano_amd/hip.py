@@ -142,6 +142,9 @@ def lib():
         L.op_match_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.op_matches_count.argtypes = [C.c_void_p, C.c_int]
         L.op_matches_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.op_matches_copy_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.op_matches_device_list.restype = C.c_void_p
+        L.op_matches_device_list.argtypes = [C.c_void_p]
         L.op_matches_total.restype = C.c_int64
         L.op_matches_total.argtypes = [C.c_void_p]
         L.op_matches_free.argtypes = [C.c_void_p]
@@ -162,6 +165,7 @@ def lib():
     L.op_ransac_inlier_count.argtypes = [C.c_void_p, C.c_int]
     L.op_ransac_inliers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.op_ransac_best.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.op_ransac_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.op_ransac_free.argtypes = [C.c_void_p]
     L.op_blend_prepare.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.POINTER(OpBlendGeom), C.c_void_p, C.c_void_p]
@@ -501,14 +505,18 @@ class Matches:
         return a
 
     def lists(self):
-        L = lib(); out = []
-        for p in range(self.npairs):
-            n = L.op_matches_count(self.handle, p)
-            a = np.empty((n, 2), np.int32)
-            if n:
-                check(L.op_matches_copy(self.handle, p, a.ctypes.data_as(C.c_void_p)))
-            out.append(a)
-        return out
+        """every pair's (M, 2) int32 list: one library call, one D2H of the resident lists"""
+        L = lib()
+        offs = np.empty(self.npairs + 1, np.int64)
+        check(L.op_matches_copy_all(self.handle, None, offs.ctypes.data_as(C.c_void_p)))
+        flat = np.empty((int(offs[-1]), 2), np.int32)
+        if len(flat):
+            check(L.op_matches_copy_all(self.handle, flat.ctypes.data_as(C.c_void_p), None))
+        return [flat[offs[p]: offs[p + 1]] for p in range(self.npairs)]
+
+    @property
+    def total(self):
+        return int(lib().op_matches_total(self.handle))
 
     @classmethod
     def from_host(cls, lists):
@@ -580,12 +588,10 @@ def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, p
     check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
                             sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
                             int(base_seed), C.byref(h)))
-    ok = 0; inl = 0
-    for p in range(len(pr)):
-        if L.op_ransac_ok(h, p):
-            ok += 1; inl += L.op_ransac_inlier_count(h, p)
+    ok = C.c_int(); inl = C.c_int64()
+    check(L.op_ransac_summary(h, C.byref(ok), C.byref(inl)))
     L.op_ransac_free(h)
-    return ok, inl
+    return ok.value, inl.value
 
 
 def match_pairs(ctx: Context, cfg, feats: Features, pairs):
@@ -596,17 +602,11 @@ def match_pairs(ctx: Context, cfg, feats: Features, pairs):
     ccfg = OpConfig.from_config(cfg)
     h = C.c_void_p()
     check(L.op_match_pairs(ctx.handle, C.byref(ccfg), feats.handle, pr.ctypes.data_as(C.c_void_p), len(pr), C.byref(h)))
-    out = []
+    mh = Matches(h, len(pr))
     try:
-        for p in range(len(pr)):
-            n = L.op_matches_count(h, p)
-            a = np.empty((n, 2), np.int32)
-            if n:
-                check(L.op_matches_copy(h, p, a.ctypes.data_as(C.c_void_p)))
-            out.append(a)
+        return [a.copy() for a in mh.lists()]
     finally:
-        L.op_matches_free(h)
-    return out
+        mh.free()
 
 
 class Canvas:

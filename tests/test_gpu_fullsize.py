@@ -5,7 +5,10 @@
   set / homography equal to the oracle's (bit-exact), the panorama within 1e-4.
   (stitcher.cc:96-113 pair loop, stitcherbase.cc:9-27 image loop.)
 * the same on natural texture (tests/natural.py: 38 crops of the reference's published uav panorama).
-* a config-5-shaped job: 32 of the 128 4000x3000 uint8 images, all 496 pairs, K ~ 3-5 k per image.
+* a config-5-shaped job: 32 of the 128 4000x3000 uint8 images, all 496 pairs, K ~ 3-5 k per image:
+  descriptors, match sets AND RANSAC (winner, inlier set, acceptance, homography) of every pair -- match lists of
+  hundreds to thousands of entries, i.e. several 512-point chunks in the hypothesis kernel and several
+  mt19937 stream chunks in the sample kernel (transform_estimate.cc:49-148, stitcher.cc:96-113).
 
 The oracle legs run on the host cores through a thread pool (ctypes drops the GIL).
 """
@@ -151,7 +154,7 @@ def test_natural_configs_1_to_3(ctx, oracle, cfg, k):
 
 def test_config5_shaped_job(ctx, oracle, cfg):
     """32 of config 5's 128 4000x3000 uint8 images (4 groups of 8 sharing a texture), device
-    resident; descriptors of every image and all 496 match sets equal the oracle's."""
+    resident; descriptors of every image, all 496 match sets and all 496 RANSAC results equal the oracle's."""
     import torch
     n = 32
     dev_imgs = synth.config5_views(range(n), torch.device("cuda", 0))
@@ -167,12 +170,16 @@ def test_config5_shaped_job(ctx, oracle, cfg):
     # images of one group overlap: true matches exist
     same = [len(lists[k]) for k, (i, j) in enumerate(pairs) if i // 8 == j // 8]
     assert np.median(same) > 50
+    # RANSAC at config-5 size: lists far beyond one 512-point chunk of k_ransac_hyp
+    assert max(len(x) for x in lists) > 1024, max(len(x) for x in lists)
+    nok = _ransac_job(ctx, oracle, cfg, feats, pairs, mh, lists, [g[1] for g in got], [(4000, 3000)] * n)
+    assert nok >= 28, nok
     mh.free(); feats.free()
 
 
 def test_config5_whole_match_job_digest(ctx, oracle, cfg):
-    """The whole config-5 match job on the device -- 128 device-resident 4000x3000 images, K ~ 4 k descriptors each,
-    all 8128 pairs in one call -- checked against the exact matcher on the host cores pair by pair (match count +
+    """The whole config-5 job on the device -- 128 device-resident 4000x3000 images, K ~ 4 k descriptors each: SIFT of
+    every image against the oracle, then all 8128 pairs in one call -- checked against the exact matcher on the host cores pair by pair (match count +
     order-free digest of the index pairs).  By default a seeded sample of 320 of the 8128 pairs is checked (the
     oracle needs ~1 core-second per pair); OPENPANO_FULL_C5=1 checks all of them (8 minutes on the GPU box's
     host: profiles/r02_config5_all_pairs_digest.txt holds that run).  The full check is what found the
@@ -183,11 +190,18 @@ def test_config5_whole_match_job_digest(ctx, oracle, cfg):
     dev_imgs = synth.config5_views(range(n), torch.device("cuda", 0))
     torch.cuda.synchronize()
     f = hip.SiftCall(ctx, cfg, [(t.data_ptr(), 3000, 4000, "u8") for t in dev_imgs])()
+    # SIFT of ALL 128 images against the oracle (descriptors and coordinates, bit for bit)
+    want = _pmap(lambda i: oracle.detect_feature((dev_imgs[i].cpu().numpy().astype(np.float64) / 255.0).astype(np.float32)), range(n))
     del dev_imgs
+    descs = []
+    for i in range(n):
+        d, c = f.get(i)
+        assert np.array_equal(d, want[i][0]) and np.array_equal(c, want[i][1]), ("image", i, len(d), len(want[i][0]))
+        descs.append(d)
+    del want
     pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
     got = hip.match_pairs(ctx, cfg, f, pairs)
     assert sum(len(g) for g in got) > 500000
-    descs = [f.get(i)[0] for i in range(n)]
     f.free()
     if os.environ.get("OPENPANO_FULL_C5") == "1":
         sel = list(range(len(pairs)))

@@ -106,6 +106,36 @@ def test_ransac_rejects_foreign_match_indices(ctx, cfg):
     bad.free(); two.free(); f.free()
 
 
+def test_large_match_lists_span_several_point_chunks(ctx, oracle, cfg):
+    """Config-5-sized pairs: thousands of matches between two images of K ~ 4 k keypoints (the hypothesis kernel
+    stages the pair's points through LDS 512 at a time, the acceptance gates walk every keypoint), planted on a
+    true homography with 35 % outliers; m = 513 / 1024 / 1025 / 2600 / 4000 sit on and across the chunk
+    boundaries.  Winner, inlier set, homography and confidence equal the oracle's."""
+    from openpano_amd import hip
+    rng = np.random.default_rng(77)
+    K, W, H = 4000, 4000, 3000
+    ca = np.stack([rng.uniform(-W / 2, W / 2, K), rng.uniform(-H / 2, H / 2, K)], 1)
+    Ht = np.array([[1.01, 0.02, 310.0], [-0.015, 0.99, -42.0], [2e-6, -1e-6, 1.0]])
+    q = np.concatenate([ca, np.ones((K, 1))], 1) @ np.linalg.inv(Ht).T
+    cb = q[:, :2] / q[:, 2:3] + rng.normal(0, 0.6, (K, 2))
+    out = rng.random(K) < 0.35
+    cb[out] = np.stack([rng.uniform(-W / 2, W / 2, out.sum()), rng.uniform(-H / 2, H / 2, out.sum())], 1)
+    f = hip.Features.from_host(ctx, [np.zeros((K, 128), np.float32)] * 2, [ca, cb])
+    sizes = [513, 1024, 1025, 2600, 4000]
+    lists = []
+    for m in sizes:
+        a = np.sort(rng.choice(K, m, replace=False)).astype(np.int32)
+        lists.append(np.stack([a, a], 1))
+    mh = hip.Matches.from_host(lists)
+    pairs = [(0, 1)] * len(sizes)
+    seeds = [500 + k for k in range(len(sizes))]
+    res = hip.ransac_pairs(ctx, cfg, f, mh, pairs, [(W, H)] * 2, seeds=seeds)
+    for k in range(len(sizes)):
+        w = _check(oracle, res[k], lists[k], ca, cb, (W, H), (W, H), seeds[k])
+        assert w["ok"] and len(w["inliers"]) > 0.5 * sizes[k]
+    mh.free(); f.free()
+
+
 def test_small_match_lists_span_several_stream_chunks(ctx, oracle, cfg):
     """With few matches almost every draw repeats an index already in the sample (m = 8: ~22 draws per
     8-point sample), so 1500 hypotheses need far more than one LDS chunk of the mt19937 stream: the

@@ -70,3 +70,25 @@ def test_affine_mode_matches_reference(oracle, ref, cfg):
     assert np.allclose(o["homo"], r["homo"], rtol=1e-7, atol=1e-9)
     assert o["homo"][2, 0] == 0 and o["homo"][2, 1] == 0 and o["homo"][2, 2] == 1   # affine
     assert _same_inliers(m, ca, cb, r["inlier_pts"], o["inliers"])
+
+
+def test_config5_sized_pair_matches_reference(oracle, ref):
+    """A pair of config-5 size: K = 4000 keypoints per image, 2600 matches on a true homography with 35 % outliers
+    (the scene tests/test_gpu_ransac.py::test_large_match_lists_span_several_point_chunks runs on the device)."""
+    rng = np.random.default_rng(77)
+    K, W, H = 4000, 4000, 3000
+    ca = np.stack([rng.uniform(-W / 2, W / 2, K), rng.uniform(-H / 2, H / 2, K)], 1)
+    Ht = np.array([[1.01, 0.02, 310.0], [-0.015, 0.99, -42.0], [2e-6, -1e-6, 1.0]])
+    q = np.concatenate([ca, np.ones((K, 1))], 1) @ np.linalg.inv(Ht).T
+    cb = q[:, :2] / q[:, 2:3] + rng.normal(0, 0.6, (K, 2))
+    out = rng.random(K) < 0.35
+    cb[out] = np.stack([rng.uniform(-W / 2, W / 2, out.sum()), rng.uniform(-H / 2, H / 2, out.sum())], 1)
+    a = np.sort(rng.choice(K, 2600, replace=False)).astype(np.int32)
+    m = np.stack([a, a], 1)
+    o = oracle.ransac(m, ca, cb, (W, H), (W, H), 502)
+    r = ref.ransac(m, ca, cb, (W, H), (W, H), 502)
+    assert o["ok"] and r["ok"] and len(o["inliers"]) > 1300
+    assert np.allclose(o["homo"], r["homo"], rtol=1e-7, atol=1e-9)
+    assert abs(o["confidence"] - r["confidence"]) < 1e-6
+    assert _same_inliers(m, ca, cb, r["inlier_pts"], o["inliers"])
+    assert np.allclose(o["homo"] / o["homo"][2, 2], Ht, rtol=0, atol=2e-2 * np.abs(Ht).clip(1e-4))
