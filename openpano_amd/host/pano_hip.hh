@@ -373,12 +373,11 @@ class HipTransformEstimation {
 		const Shape2D shape1, shape2;
 };
 
-// Body of Stitcher::pairwise_match / linear_pairwise_match + match_image (stitch/stitcher.cc:66-136)
-// for a whole task list: ONE matcher call and ONE batched RANSAC call.  out[k] = (succ, info of
-// tasks[k], homography from j to i) -- the caller keeps the reference's bookkeeping
-// (pairwise_matches[i][j] / inverse for [j][i], stitcher.cc:79-93).
-inline std::vector<std::pair<bool, MatchInfo>> hip_match_images(const HipFeatureSet& fs,
-		const std::vector<Shape2D>& shapes, const std::vector<std::pair<int, int>>& tasks, uint32_t base_seed) {
+// One op_match_pairs + one op_ransac_pairs for a whole task list; pair p's RANSAC seed is seeds[p] (or derived from
+// base_seed and p when seeds is empty).  The match lists never leave the device between the two calls; they come
+// to the host once, for MatchInfo::match and the caller's MatchData.
+inline void hip_match_and_estimate(const HipFeatureSet& fs, const std::vector<Shape2D>& shapes, const std::vector<std::pair<int, int>>& tasks,
+		const std::vector<uint32_t>& seeds, uint32_t base_seed, std::vector<MatchData>& matches, std::vector<std::pair<bool, MatchInfo>>& out) {
 	op_ctx* ctx = HipContext::get();
 	const op_config cfg = hip_config_snapshot();
 	std::vector<int> pr, sh;
@@ -387,20 +386,89 @@ inline std::vector<std::pair<bool, MatchInfo>> hip_match_images(const HipFeature
 	op_matches* m = nullptr;
 	PANO_HIP_CHECK(op_match_pairs(ctx, &cfg, fs.handle, pr.data(), (int)tasks.size(), &m));
 	op_ransac_result* r = nullptr;
-	PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), nullptr, base_seed, &r));
-	std::vector<std::pair<bool, MatchInfo>> out(tasks.size());
+	PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), seeds.empty() ? nullptr : seeds.data(), base_seed, &r));
+	std::vector<int64_t> off(tasks.size() + 1);
+	std::vector<int> idx((size_t)op_matches_total(m) * 2 + 2);
+	PANO_HIP_CHECK(op_matches_copy_all(m, idx.data(), off.data()));
+	matches.assign(tasks.size(), MatchData());
+	out.assign(tasks.size(), std::pair<bool, MatchInfo>());
+	std::vector<std::vector<Vec2D>> kps(fs.feats.size());
+	for (size_t k = 0; k < fs.feats.size(); ++k) { kps[k].reserve(fs.feats[k].size()); for (auto& d : fs.feats[k]) kps[k].push_back(d.coor); }
 	for (size_t p = 0; p < tasks.size(); ++p) {
-		const int c = op_matches_count(m, (int)p);
-		std::vector<int> idx((size_t)c * 2 + 2);
-		if (c) PANO_HIP_CHECK(op_matches_copy(m, (int)p, idx.data()));
-		MatchData md;
-		for (int q = 0; q < c; ++q) md.data.emplace_back(idx[2 * q], idx[2 * q + 1]);
-		std::vector<Vec2D> k1, k2;
-		for (auto& d : fs.feats[tasks[p].first]) k1.push_back(d.coor);
-		for (auto& d : fs.feats[tasks[p].second]) k2.push_back(d.coor);
-		out[p].first = HipTransformEstimation::fill(r, (int)p, md, k1, k2, &out[p].second);
+		MatchData& md = matches[p];
+		md.data.reserve((size_t)(off[p + 1] - off[p]));
+		for (int64_t q = off[p]; q < off[p + 1]; ++q) md.data.emplace_back(idx[2 * q], idx[2 * q + 1]);
+		out[p].first = HipTransformEstimation::fill(r, (int)p, md, kps[tasks[p].first], kps[tasks[p].second], &out[p].second);
 	}
 	op_ransac_free(r); op_matches_free(m);
+}
+
+// ---- the batched hooks inside the reference's OWN loops ("batched form") ----
+// Stitcher::pairwise_match / linear_pairwise_match (stitch/stitcher.cc:96-136) construct one matcher and then call
+// match_image(pwmatcher, i, j) per task from an OpenMP loop; match_image (:66-94) asks the matcher for the pair's
+// MatchData, runs a TransformEstimation on it and keeps the bookkeeping.  HipBatchedMatcher has PairWiseMatcher's
+// place and match(i, j) signature, but its constructor runs the WHOLE default task list (all i < j, or (i, i + 1)
+// under ORDERED_INPUT: the lists of :99-100 / :121-124) through one op_match_pairs + one op_ransac_pairs; match()
+// returns a MatchData that remembers where its pair's RANSAC result lies, and HipBatchedTransformEstimation -- in
+// TransformEstimation's place, same constructor and get_transform -- hands that result over.  The reference's loop
+// bodies stay as they are.
+struct HipMatchData : public MatchData {
+	const std::pair<bool, MatchInfo>* estimated = nullptr;
+};
+class HipBatchedMatcher {
+	public:
+		// imgs: anything with shape() per image (std::vector<ImageRef>, stitcherbase.hh:28)
+		template <typename ImageList>
+		HipBatchedMatcher(const HipFeatureSet& fs, const ImageList& imgs) {
+			const int n = (int)fs.feats.size();
+			if (config::ORDERED_INPUT) for (int i = 0; i < n; ++i) tasks.emplace_back(i, (i + 1) % n);         // stitcher.cc:121-124
+			else for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) tasks.emplace_back(i, j);          // stitcher.cc:99-100
+			std::vector<Shape2D> shapes;
+			for (auto& r : imgs) shapes.push_back(r.shape());
+			// the reference seeds every get_transform from std::random_device (transform_estimate.cc:64-65)
+			std::vector<uint32_t> seeds(tasks.size());
+			for (auto& s : seeds) s = HipTransformEstimation::seed_injected() ? HipTransformEstimation::injected_seed() : std::random_device{}();
+			hip_match_and_estimate(fs, shapes, tasks, seeds, 0, matches, results);
+			for (size_t p = 0; p < tasks.size(); ++p) index[tasks[p]] = p;
+		}
+		HipBatchedMatcher(const HipBatchedMatcher&) = delete;
+		HipBatchedMatcher& operator=(const HipBatchedMatcher&) = delete;
+		// return pair of <idx in i, idx in j>, plus the pair's transform estimate
+		HipMatchData match(int i, int j) const {
+			auto it = index.find(std::make_pair(i, j));
+			if (it == index.end()) { fprintf(stderr, "HipBatchedMatcher: pair (%d, %d) is not in the task list\n", i, j); exit(1); }
+			HipMatchData md;
+			md.data = matches[it->second].data;
+			md.estimated = &results[it->second];
+			return md;
+		}
+	private:
+		std::vector<std::pair<int, int>> tasks;
+		std::vector<MatchData> matches;
+		std::vector<std::pair<bool, MatchInfo>> results;
+		std::map<std::pair<int, int>, size_t> index;
+};
+class HipBatchedTransformEstimation {
+	public:
+		HipBatchedTransformEstimation(const HipMatchData& m_match, const std::vector<Vec2D>&, const std::vector<Vec2D>&, const Shape2D&, const Shape2D&):
+			match(m_match) {}
+		bool get_transform(MatchInfo* info) {
+			*info = match.estimated->second;
+			return match.estimated->first;
+		}
+	private:
+		const HipMatchData& match;
+};
+
+// Body of Stitcher::pairwise_match / linear_pairwise_match + match_image (stitch/stitcher.cc:66-136)
+// for a whole task list: ONE matcher call and ONE batched RANSAC call.  out[k] = (succ, info of
+// tasks[k], homography from j to i) -- the caller keeps the reference's bookkeeping
+// (pairwise_matches[i][j] / inverse for [j][i], stitcher.cc:79-93).
+inline std::vector<std::pair<bool, MatchInfo>> hip_match_images(const HipFeatureSet& fs,
+		const std::vector<Shape2D>& shapes, const std::vector<std::pair<int, int>>& tasks, uint32_t base_seed) {
+	std::vector<MatchData> matches;
+	std::vector<std::pair<bool, MatchInfo>> out;
+	hip_match_and_estimate(fs, shapes, tasks, std::vector<uint32_t>(), base_seed, matches, out);
 	return out;
 }
 

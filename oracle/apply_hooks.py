@@ -36,14 +36,15 @@ def rename_classes(text, prefix):
 
 
 def must_sub(pattern, repl, text, name, count_min=1):
-    new, n = re.subn(pattern, repl, text)
+    new, n = re.subn(pattern, repl, text, flags=re.S)
     if n < count_min:
         raise SystemExit(f"apply_hooks: pattern {pattern!r} matched {n} time(s) in {name} (expected >= {count_min}): the reference changed")
     return new
 
 
-def variant_exact(name, text):
-    text = rename_classes(text, "Exact")
+def variant_exact(name, text, rename=True):
+    if rename:
+        text = rename_classes(text, "Exact")
     if name in ("stitcher.hh", "stitcher.cc", "cylstitcher.cc"):
         text = must_sub(r"\bPairWiseMatcher\b", "ExactPairWiseMatcher", text, name)
     if name == "stitcherbase.hh":
@@ -51,32 +52,74 @@ def variant_exact(name, text):
     return text
 
 
-def variant_hip(name, text):
-    text = rename_classes(text, "Hooked")
+def variant_hip(name, text, prefix="Hooked", fast=False):
+    """the five construction-site hooks; fast=True: INTEGRATION.md's batched forms on top (hooks 1b, 2b, 3b)"""
+    if prefix:
+        text = rename_classes(text, prefix)
+    base = (prefix or "") + "StitcherBase"
     if name == "stitcherbase.hh":
         text = must_sub(r'#include "feature/feature.hh"', '#include "feature/feature.hh"\n#include "pano_hip.hh"', text, name)
         text = must_sub(r"new SIFTDetector\b", "new HipSIFTDetector", text, name)                         # hook 1
-    if name in ("stitcher.hh", "stitcher.cc", "cylstitcher.cc"):
-        text = must_sub(r"\bPairWiseMatcher\b", "HipPairWiseMatcher", text, name)                          # hook 2
+        if fast:                                                                                          # hook 1b: the resident feature set
+            text = must_sub(r"(std::vector<std::vector<Descriptor>> feats;)", r"\1\n\t\tHipFeatureSet hip_feats;\t// the same features, resident in HBM", text, name)
+    if name == "stitcherbase.cc" and fast:
+        # hook 1b: body of calc_feature() (stitcherbase.cc:9-27) = one batched device call for all images
+        body = (
+            "  std::vector<const Mat32f*> ptrs;\n"
+            "  for (auto& r : imgs) { r.load(); ptrs.push_back(r.img); }\n"
+            "  hip_feats = static_cast<HipSIFTDetector&>(*feature_det).calc_feature(ptrs);\n"
+            "  feats = hip_feats.feats;\n"
+            "  REP(k, (int)imgs.size()) {\n"
+            "    if (config::LAZY_READ) imgs[k].release();\n"
+            "    print_debug(\"Image %d has %lu features\\n\", k, feats[k].size());\n"
+            "    keypoints[k].resize(feats[k].size());\n"
+            "    REP(i, feats[k].size()) keypoints[k][i] = feats[k][i].coor;\n"
+            "  }\n}\n")
+        text = must_sub(r"#pragma omp parallel for schedule\(dynamic\)\s*\n\s*REP\(k, \(int\)imgs\.size\(\)\) \{.*?\n  \}\n\}\n", lambda m: body, text, name)
+    if name in ("stitcher.hh", "stitcher.cc"):
+        if fast:                                                                                          # hook 2b
+            text = must_sub(r"\bPairWiseMatcher pwmatcher\(feats\)", "HipBatchedMatcher pwmatcher(hip_feats, imgs)", text, name, 2 if name == "stitcher.cc" else 0)
+            text = must_sub(r"\bPairWiseMatcher\b", "HipBatchedMatcher", text, name)
+        else:
+            text = must_sub(r"\bPairWiseMatcher\b", "HipPairWiseMatcher", text, name)                     # hook 2
+    if name == "cylstitcher.cc":
+        if fast:                                                                                          # descriptors already resident: no second H2D
+            text = must_sub(r"\bPairWiseMatcher pwmatcher\(feats\)", "HipPairWiseMatcher pwmatcher(hip_feats)", text, name)
+        else:
+            text = must_sub(r"\bPairWiseMatcher\b", "HipPairWiseMatcher", text, name)
     if name in ("stitcher.cc", "cylstitcher.cc"):
-        text = must_sub(r"(?<![\w:])TransformEstimation(\s*\(|\s+transf\s*\()", r"HipTransformEstimation\1", text, name)   # hook 3
+        te = "HipBatchedTransformEstimation" if (fast and name == "stitcher.cc") else "HipTransformEstimation"   # hook 3 / 3b
+        text = must_sub(r"(?<![\w:])TransformEstimation(\s*\(|\s+transf\s*\()", te + r"\1", text, name)
         text = must_sub(r"\bbundle\.blend\(\)", "hip_blend(bundle)", text, name)                            # hook 4
     if name == "cylstitcher.cc":
         text = must_sub(r"\bCylinderWarper warper\b", "HipCylinderWarper warper", text, name, 2)            # hook 5
     return text
 
 
+VARIANTS = {
+    # one test process holds exact + hip + hipfast next to the untouched classes: renamed
+    "exact": lambda n, t: variant_exact(n, t),
+    "hip": lambda n, t: variant_hip(n, t, "Hooked", False),
+    "hipfast": lambda n, t: variant_hip(n, t, "Batched", True),
+    # what a maintainer's tree looks like (no renames): the reference's main.cc is compiled against these
+    "cli_exact": lambda n, t: variant_exact(n, t, rename=False),
+    "cli_hip": lambda n, t: variant_hip(n, t, None, False),
+    "cli_hipfast": lambda n, t: variant_hip(n, t, None, True),
+}
+
+
 def main():
     ref, out = sys.argv[1], sys.argv[2]
-    for var, fn in (("exact", variant_exact), ("hip", variant_hip)):
-        d = os.path.join(out, var)
+    for var, fn in VARIANTS.items():
+        # cli_* variants mirror the tree layout (stitch/...) so that main.cc's #include "stitch/stitcher.hh" finds them
+        d = os.path.join(out, var, "stitch") if var.startswith("cli_") else os.path.join(out, var)
         os.makedirs(d, exist_ok=True)
         for name in FILES:
             text = open(os.path.join(ref, "src", "stitch", name)).read()
             with open(os.path.join(d, name), "w") as f:
                 f.write(f"// GENERATED by oracle/apply_hooks.py ({var}) from the reference's src/stitch/{name} -- build output, never committed\n")
                 f.write(fn(name, text))
-    print(f"apply_hooks: wrote {out}/exact and {out}/hip")
+    print(f"apply_hooks: wrote {', '.join(VARIANTS)} under {out}")
 
 
 if __name__ == "__main__":

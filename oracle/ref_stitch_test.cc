@@ -7,7 +7,9 @@
 //            ConnectedImages::blend, CameraEstimator), made deterministic: exact FeatureMatcher
 //            instead of the FLANN forest, injected mt19937 seed;
 //   Hooked*  the same files with INTEGRATION.md's five construction-site edits, i.e. the HIP library
-//            behind the reference's loops --
+//            behind the reference's loops (one image per SIFT call, one pair per RANSAC call);
+//   Batched* the same files with INTEGRATION.md's batched hooks: calc_feature() is ONE op_sift_batch, the
+//            matcher object runs the whole task list through ONE op_match_pairs + ONE op_ransac_pairs --
 // and run on the same image files in one process.  Compared: the "Final Image Size" of
 // stitcher_image.cc:124 (canvas dimensions) and every pixel of the panorama (<= 1e-4, north_star).
 //   ref_stitch_test <cylinder|camera|camera_ordered|trans> <seed> <multiband> img0.png img1.png ...
@@ -23,6 +25,9 @@
 #include "exact/cylstitcher.hh"
 #include "hip/stitcher.hh"
 #include "hip/cylstitcher.hh"
+#include "hipfast/stitcher.hh"
+#include "hipfast/cylstitcher.hh"
+#include <chrono>
 #include "lib/imgproc.hh"
 
 using namespace pano;
@@ -82,35 +87,56 @@ int main(int argc, char** argv) {
 	ref_set_seed(seed);
 	HipTransformEstimation::seed_injected() = true; HipTransformEstimation::injected_seed() = seed;
 
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	// "time" as the seed argument's suffix (e.g. 38t): the CPU leg runs on all host threads (its outputs then depend
+	// on thread timing, extrema.cc:56 -- sizes only are compared) and every variant's build() wall time is printed
+	const bool timing = strchr(argv[2], 't') != nullptr;
+	if (timing) { omp_set_num_threads(omp_get_num_procs()); ref_set_threads(omp_get_num_procs()); }
 	printf("[reference orchestration, CPU, %zu images, mode %s]\n", files.size(), mode.c_str()); fflush(stdout);
+	double t0 = now();
 	Mat32f want = cyl ? ExactCylinderStitcher(files).build() : ExactStitcher(files).build();
-	printf("[reference orchestration + the five hooks -> libopenpano_hip.so]\n"); fflush(stdout);
-	Mat32f got = cyl ? HookedCylinderStitcher(files).build() : HookedStitcher(files).build();
-
+	const double t_cpu = now() - t0;
 	int fail = 0;
-	printf("FINAL_SIZE reference %dx%d hooked %dx%d\n", want.width(), want.height(), got.width(), got.height());
-	if (want.rows() != got.rows() || want.cols() != got.cols()) { printf("FAIL: canvas size differs\n"); return 1; }
-	const long n = (long)want.rows() * want.cols();
-	long mask_diff = 0, exact = 0, valid = 0; double maxd = 0;
-	for (long e = 0; e < n; ++e) {
-		const float* p = want.ptr() + e * 3; const float* q = got.ptr() + e * 3;
-		const bool na = p[0] < 0, nb = q[0] < 0;
-		if (na != nb) { ++mask_diff; continue; }
-		if (na) continue;
-		++valid;
-		bool eq = true;
-		for (int c = 0; c < 3; ++c) { maxd = std::max(maxd, (double)fabsf(p[c] - q[c])); eq &= (p[c] == q[c]); }
-		exact += eq;
-	}
-	printf("PANORAMA covered %.1f%%, max |diff| %.3g, bit-equal %.4f%%, no-pixel mask flips %ld\n", 100.0 * valid / n, maxd,
-			100.0 * exact / std::max(1L, valid), mask_diff);
-	if (!(maxd <= 1e-4)) { printf("FAIL: max diff %g > 1e-4\n", maxd); ++fail; }
-	if (mask_diff > n / 20000 + 2) { printf("FAIL: %ld mask flips\n", mask_diff); ++fail; }
-	if (valid < n / 4) { printf("FAIL: canvas barely covered\n"); ++fail; }
-	// main.cc:226-229: crop under config CROP -- same rectangle from both
-	Mat32f cw = crop(want), cg = crop(got);
-	printf("CROPPED reference %dx%d hooked %dx%d\n", cw.width(), cw.height(), cg.width(), cg.height());
-	if (cw.rows() != cg.rows() || cw.cols() != cg.cols()) { printf("FAIL: crop rectangle differs\n"); ++fail; }
+	auto compare = [&](const char* what, const Mat32f& got) {
+		printf("FINAL_SIZE reference %dx%d %s %dx%d\n", want.width(), want.height(), what, got.width(), got.height());
+		if (timing) return;      // a multi-threaded CPU leg orders its keypoints by thread timing (extrema.cc:56): its RANSAC draws differ
+		if (want.rows() != got.rows() || want.cols() != got.cols()) { printf("FAIL: canvas size differs\n"); ++fail; return; }
+		const long n = (long)want.rows() * want.cols();
+		long mask_diff = 0, exact = 0, valid = 0; double maxd = 0;
+		for (long e = 0; e < n; ++e) {
+			const float* p = want.ptr() + e * 3; const float* q = got.ptr() + e * 3;
+			const bool na = p[0] < 0, nb = q[0] < 0;
+			if (na != nb) { ++mask_diff; continue; }
+			if (na) continue;
+			++valid;
+			bool eq = true;
+			for (int c = 0; c < 3; ++c) { maxd = std::max(maxd, (double)fabsf(p[c] - q[c])); eq &= (p[c] == q[c]); }
+			exact += eq;
+		}
+		printf("PANORAMA %s covered %.1f%%, max |diff| %.3g, bit-equal %.4f%%, no-pixel mask flips %ld\n", what, 100.0 * valid / n, maxd,
+				100.0 * exact / std::max(1L, valid), mask_diff);
+		if (!(maxd <= 1e-4)) { printf("FAIL: max diff %g > 1e-4\n", maxd); ++fail; }
+		if (mask_diff > n / 20000 + 2) { printf("FAIL: %ld mask flips\n", mask_diff); ++fail; }
+		if (valid < n / 4) { printf("FAIL: canvas barely covered\n"); ++fail; }
+		// main.cc:226-229: crop under config CROP -- same rectangle from both
+		Mat32f cw = crop(want), cg = crop(got);
+		printf("CROPPED reference %dx%d %s %dx%d\n", cw.width(), cw.height(), what, cg.width(), cg.height());
+		if (cw.rows() != cg.rows() || cw.cols() != cg.cols()) { printf("FAIL: crop rectangle differs\n"); ++fail; }
+	};
+	// the device library is warm for the timed runs (context, kernels, pools): one throw-away build in timing mode
+	if (timing) { if (cyl) BatchedCylinderStitcher(files).build(); else BatchedStitcher(files).build(); }
+	printf("[reference orchestration + the five hooks -> libopenpano_hip.so]\n"); fflush(stdout);
+	t0 = now();
+	Mat32f got = cyl ? HookedCylinderStitcher(files).build() : HookedStitcher(files).build();
+	const double t_hook = now() - t0;
+	compare("hooked", got);
+	printf("[reference orchestration + the batched hooks -> libopenpano_hip.so]\n"); fflush(stdout);
+	t0 = now();
+	Mat32f got2 = cyl ? BatchedCylinderStitcher(files).build() : BatchedStitcher(files).build();
+	const double t_batch = now() - t0;
+	compare("batched", got2);
+	printf("DROPIN_MS {\"images\": %zu, \"mode\": \"%s\", \"cpu_threads\": %d, \"reference_cpu_build_ms\": %.1f, \"five_hooks_build_ms\": %.1f, \"batched_hooks_build_ms\": %.1f}\n",
+			files.size(), mode.c_str(), timing ? omp_get_num_procs() : 1, t_cpu, t_hook, t_batch);
 	printf(fail ? "STITCH DROPIN FAILED\n" : "STITCH DROPIN OK\n");
 	return fail ? 1 : 0;
 }

@@ -210,6 +210,105 @@ def test_reference_orchestration_dropin(tmp_path, name, mode, mb, cfgk, n):
                        cwd=os.path.dirname(STITCH_DROPIN))
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "STITCH DROPIN OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
-    # both builds printed the line the reference's own run_test.py scrapes, with the same size
+    assert "PANORAMA hooked" in r.stdout and "PANORAMA batched" in r.stdout          # five-hook and batched-hook variants both ran
+    # all three builds printed the line the reference's own run_test.py scrapes, with the same size
     sizes = [ln.split("Final Image Size:")[1].strip() for ln in r.stderr.splitlines() if "Final Image Size:" in ln]
-    assert len(sizes) == 2 and sizes[0] == sizes[1], sizes
+    assert len(sizes) == 3 and sizes[0] == sizes[1] == sizes[2], sizes
+
+
+def test_reference_orchestration_dropin_timing(tmp_path):
+    """BASELINE config 4 on natural texture (38 unordered 1300x867 views) through the reference's own
+    Stitcher::build(): CPU on every host thread, the five hooks, the batched hooks -- same canvas size, and the
+    wall time of each build() (the DROPIN_MS line; profiles/ keeps one)."""
+    import json
+    import natural
+    if not os.path.exists(STITCH_DROPIN):
+        pytest.skip("oracle/_ref/ref_stitch_test not built (reference sources absent at build time)")
+    if not natural.available():
+        pytest.skip("tests/golden/natural or PIL missing")
+    from PIL import Image
+    files = []
+    for k, v in enumerate(natural.config_views(4)):
+        p = str(tmp_path / f"{k:02d}.png")
+        Image.fromarray(v).save(p)
+        files.append(p)
+    r = subprocess.run([STITCH_DROPIN, "camera", "38t", "0"] + files, capture_output=True, text=True, env=_env(), timeout=1800,
+                       cwd=os.path.dirname(STITCH_DROPIN))
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "STITCH DROPIN OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("DROPIN_MS")][0]
+    ms = json.loads(line[len("DROPIN_MS"):])
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "dropin_ms.json"), "w") as f:
+            json.dump(ms, f)
+    assert ms["batched_hooks_build_ms"] < ms["five_hooks_build_ms"] < ms["reference_cpu_build_ms"], ms
+
+
+# ---- the literal CLI: the reference's own main.cc (main.cc:205-235 work(), :237-292 init_config, :333-357 main) ----
+CLI_CPU = os.path.join(ROOT, "oracle", "_ref", "image-stitching")
+CLI_CASES = [
+    # (id, config.cfg overrides, natural-config, views): BASELINE config 1 (2 x 600x400 CYLINDER) and config 2 (11 x 600x400 ESTIMATE_CAMERA, ordered)
+    ("config1_cylinder_2x600x400", dict(CYLINDER=1, ESTIMATE_CAMERA=0, ORDERED_INPUT=1), 1, 2),
+    ("config2_camera_11x600x400", dict(ORDERED_INPUT=1), 2, 11),
+    ("camera_unordered_5x600x400", dict(), 2, 5),
+]
+
+
+def _write_config_cfg(path, **over):
+    """config.cfg as ConfigParser reads it (lib/config.cc:13-29): the shipped defaults with overrides"""
+    from openpano_amd.config import DEFAULTS
+    vals = dict(DEFAULTS); vals.update(over)
+    with open(path, "w") as f:
+        for k, v in vals.items():
+            f.write(f"{k} {v}\n")
+
+
+def _run_cli(binary, cwd, files, threads):
+    env = _env()
+    env["OPENPANO_TEST_SEED"] = "38"                      # oracle/cli_seed_seam.cc: what random_device returns
+    env["OMP_NUM_THREADS"] = str(threads)
+    r = subprocess.run([binary] + files, capture_output=True, text=True, env=env, timeout=900, cwd=cwd)
+    assert r.returncode == 0, (binary, r.stdout[-2000:], r.stderr[-3000:])
+    out = r.stdout + r.stderr                              # print_debug goes to stderr, GuardedTimer to stdout
+    size = [ln.split("Final Image Size:")[1].strip() for ln in out.splitlines() if "Final Image Size:" in ln]
+    crop = [ln.split("Crop from")[1].strip() for ln in out.splitlines() if "Crop from" in ln]
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(cwd, "out.png")).convert("RGB")).copy()
+    return size, crop, img
+
+
+@pytest.mark.parametrize("name,over,cfgk,n", CLI_CASES, ids=[c[0] for c in CLI_CASES])
+@pytest.mark.parametrize("variant", ["hip", "hipfast"])
+def test_reference_cli_dropin(tmp_path, variant, name, over, cfgk, n):
+    """north_star: "so the image-stitching CLI is a drop-in".  The reference's own main.cc compiled against its own
+    sources (CPU; exact matcher + seeded random_device so that it is reproducible) and against the same sources with
+    INTEGRATION.md's hooks -- the five construction-site edits (`hip`) or the batched forms (`hipfast`) -- run as the
+    reference is run: `image-stitching a.png b.png ...` with a config.cfg in the working directory, result in
+    out.png.  Same Final Image Size line, same crop, same bytes up to one quantisation level (write_rgb truncates
+    v * 255: a 1e-4 difference may cross an integer)."""
+    import natural
+    hooked = os.path.join(ROOT, "oracle", "_ref", "image-stitching-" + variant)
+    if not (os.path.exists(CLI_CPU) and os.path.exists(hooked)):
+        pytest.skip("oracle/_ref/image-stitching* not built (reference sources absent at build time)")
+    if not natural.available():
+        pytest.skip("tests/golden/natural or PIL missing")
+    from PIL import Image
+    res = []
+    for binary, sub, threads in ((CLI_CPU, "cpu", 1), (hooked, variant, 8)):
+        d = tmp_path / sub
+        d.mkdir()
+        files = []
+        for k, v in enumerate(natural.config_views(cfgk, n)):
+            p = str(d / f"{k:02d}.png")
+            Image.fromarray(v).save(p)
+            files.append(p)
+        _write_config_cfg(str(d / "config.cfg"), LAZY_READ=0, **over)
+        res.append(_run_cli(binary, str(d), files, threads))
+    (s0, c0, a), (s1, c1, b) = res
+    assert len(s0) == 1 and s0 == s1, (s0, s1)
+    assert c0 == c1 and len(c0) == 1, (c0, c1)
+    assert a.shape == b.shape and a.shape[0] > 100 and a.shape[1] > 300
+    diff = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert diff.max() <= 1, int(diff.max())
+    assert (diff == 0).mean() > 0.999, float((diff == 0).mean())
