@@ -65,8 +65,10 @@ def variant_hip(name, text, prefix="Hooked", fast=False):
     if name == "stitcherbase.cc" and fast:
         # hook 1b: body of calc_feature() (stitcherbase.cc:9-27) = one batched device call for all images
         body = (
+            "#pragma omp parallel for schedule(dynamic)\n"
+            "  REP(k, (int)imgs.size()) imgs[k].load();          // decode in parallel, as the reference's loop does\n"
             "  std::vector<const Mat32f*> ptrs;\n"
-            "  for (auto& r : imgs) { r.load(); ptrs.push_back(r.img); }\n"
+            "  for (auto& r : imgs) ptrs.push_back(r.img);\n"
             "  hip_feats = static_cast<HipSIFTDetector&>(*feature_det).calc_feature(ptrs);\n"
             "  feats = hip_feats.feats;\n"
             "  REP(k, (int)imgs.size()) {\n"

@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
 		if (cw.rows() != cg.rows() || cw.cols() != cg.cols()) { printf("FAIL: crop rectangle differs\n"); ++fail; }
 	};
 	// the device library is warm for the timed runs (context, kernels, pools): one throw-away build in timing mode
-	if (timing) { if (cyl) BatchedCylinderStitcher(files).build(); else BatchedStitcher(files).build(); }
+	if (timing) { printf("[warm-up of the device library, not timed]\n"); fflush(stdout); if (cyl) BatchedCylinderStitcher(files).build(); else BatchedStitcher(files).build(); }
 	printf("[reference orchestration + the five hooks -> libopenpano_hip.so]\n"); fflush(stdout);
 	t0 = now();
 	Mat32f got = cyl ? HookedCylinderStitcher(files).build() : HookedStitcher(files).build();
