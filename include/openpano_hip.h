@@ -130,10 +130,11 @@ void op_features_free(op_features* f);
 /* Staged single-image run keeping every intermediate (the debug commands raw_extrema /
  * keypoint / orientation of main.cc:41-81 and the per-stage parity tests).
  * plane kinds: 1 DoG[s] (s in 0..nscale-2), 2 mag[s], 3 ort[s] (s in 1..nscale-3),
- *              4 working RGB, 5 grey octave base, 6 Gaussian[s] (s in 1..nscale-3).
- * mag/ort are not materialised by op_sift_batch (the orientation / descriptor kernels evaluate
- * GaussianPyramid::cal_mag_ort, feature/dog.cc:60-94, on the Gaussian plane for the samples they
- * use); the dump computes those two planes on request. */
+ *              4 working RGB, 5 grey octave base, 6 Gaussian[s] (s in 1..nscale-1).
+ * Only the Gaussian stack reaches HBM in op_sift_batch: DoG planes live in LDS for the extrema scan and are
+ * re-evaluated as |G[s] - G[s+1]| (feature/dog.cc:126) where the refinement needs them; mag/ort are evaluated
+ * by the orientation / descriptor kernels (GaussianPyramid::cal_mag_ort, feature/dog.cc:60-94) on the Gaussian
+ * plane for the samples they use.  The dump computes DoG, mag and ort planes on request. */
 typedef struct op_sift_dump op_sift_dump;
 int op_sift_staged(op_ctx* ctx, const op_config* cfg, const op_image* img, op_sift_dump** out);
 void op_sift_dump_free(op_sift_dump* d);

@@ -89,12 +89,14 @@ void pool_trim();     // release every cached block back to the runtime
 
 // ---------------------------------------------------------------------------------------
 // HBM layout of one image's scale space ("image workspace", ws_stride floats per image):
-//   for each octave o:  [grey][DoG 0 .. ns-2][gauss 1 .. ns-3]   each h_o*w_o fp32, row-major,
-// octave blocks back to back.  Of the reference's Gaussian stack (feature/dog.cc:53-57) only the
-// planes whose gradients are ever read (scale_id in [1, ns-3]: extrema.cc:75, orientation.cc:37,
-// sift.cc:96) reach HBM; the mag/ort planes of GaussianPyramid::cal_mag_ort (dog.cc:60-94) are
-// never materialised -- the orientation and descriptor kernels evaluate the same expressions on
-// the Gaussian plane for exactly the window samples they use.
+//   for each octave o:  [G 0 = grey][G 1 .. G ns-1]   each h_o*w_o fp32, row-major, octave blocks back to back
+// -- the reference's Gaussian stack (feature/dog.cc:53-57: data[0] is the unblurred grey image) and NOTHING else.
+// The DoG planes (dog.cc:116-129) are never materialised: the extrema scan runs on them while they are in LDS
+// (pyramid.hip), and the sub-pixel refinement -- the only other reader, a few hundred sparse 3x3x3 neighbourhoods per
+// image -- evaluates |G[l] - G[l+1]| (dog.cc:126) on the two Gaussian planes, the same fp32 operation on the same
+// operands: 28 bytes per octave pixel cross the HBM boundary in the scale-space kernel instead of 44.  The mag/ort
+// planes of GaussianPyramid::cal_mag_ort (dog.cc:60-94) are not materialised either -- the orientation and
+// descriptor kernels evaluate the same expressions on the Gaussian plane for exactly the window samples they use.
 // ---------------------------------------------------------------------------------------
 struct OctDesc {
 	int h, w;
@@ -135,9 +137,8 @@ struct SiftPlan {
 };
 
 __host__ __device__ inline long long plane_off_grey(const OctDesc& o) { return o.off; }
-__host__ __device__ inline long long plane_off_dog(const OctDesc& o, int s) { return o.off + (1 + s) * o.plane; }
-__host__ __device__ inline long long plane_off_gauss(const OctDesc& o, int ns, int s) { return o.off + (1 + (ns - 1) + (s - 1)) * o.plane; }
-__host__ __device__ inline int planes_per_octave(int ns) { return 1 + (ns - 1) + (ns - 3); }
+__host__ __device__ inline long long plane_off_gauss(const OctDesc& o, int ns, int s) { (void)ns; return o.off + (long long)s * o.plane; }   // s = 0: grey
+__host__ __device__ inline int planes_per_octave(int ns) { return ns; }
 
 // a scale-space point (feature/feature.hh:33-39), 48 bytes
 struct KeyPoint {

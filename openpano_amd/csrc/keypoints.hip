@@ -9,9 +9,15 @@
 
 namespace {
 
-__device__ __forceinline__ const float* dog_plane(const SiftPlan& p, int img, int o, int s) {
-	return p.ws + (long long)img * p.ws_stride + plane_off_dog(p.oct[o], s);
-}
+// DoG layer l at pixel c (feature/dog.cc:126): the planes are not materialised, the value is the same fp32
+// |G[l] - G[l+1]| evaluated on the Gaussian stack (G[0] = grey), whose planes lie `plane` floats apart
+struct DogView {
+	const float* g0; long long plane;
+	__device__ __forceinline__ float operator()(int l, long long c) const {
+		const float* a = g0 + (long long)l * plane + c;
+		return fabsf(a[0] - a[plane]);
+	}
+};
 
 // Eigen::FullPivLU 3x3 inverse as used by Matrix::inverse (lib/matrix.cc:76-87): complete
 // pivoting, rank threshold |pivot| > |maxpivot| * eps * 3, inverse = solve(Identity).
@@ -107,27 +113,28 @@ __global__ void __launch_bounds__(128) k_refine(SiftPlan p, const int* raw, cons
 	const OctDesc od = p.oct[o];
 	const int w = od.w, h = od.h, nscale = p.nscale;
 	const float* base = p.ws + (long long)img * p.ws_stride;
+	const DogView dog{base + plane_off_gauss(od, nscale, 0), od.plane};
 	double offset[3] = {0, 0, 0}, delta[3] = {0, 0, 0};
 	int niter = 0;
 	for (; niter < p.calc_offset_depth; ++niter) {
 		if (!(nowx >= 1 && nowx <= w - 2) || !(nowy >= 1 && nowy <= h - 2) || !(nows >= 1 && nows <= nscale - 3))
 			return;
-		const float* d0 = base + plane_off_dog(od, nows - 1);
-		const float* d1 = base + plane_off_dog(od, nows);
-		const float* d2 = base + plane_off_dog(od, nows + 1);
 		const long long c = (long long)nowy * w + nowx;
-		const float val = d1[c];
-		const float xp = d1[c + 1], xm = d1[c - 1], yp = d1[c + w], ym = d1[c - w];
-		const float sp = d2[c], sm = d0[c];
+		auto d0 = [&](long long i) { return dog(nows - 1, i); };
+		auto d1 = [&](long long i) { return dog(nows, i); };
+		auto d2 = [&](long long i) { return dog(nows + 1, i); };
+		const float val = d1(c);
+		const float xp = d1(c + 1), xm = d1(c - 1), yp = d1(c + w), ym = d1(c - w);
+		const float sp = d2(c), sm = d0(c);
 		delta[0] = (double)((xp - xm) / 2);
 		delta[1] = (double)((yp - ym) / 2);
 		delta[2] = (double)((sp - sm) / 2);
 		const double dxx = (double)(xp + xm - val - val);
 		const double dyy = (double)(yp + ym - val - val);
 		const double dss = (double)(sp + sm - val - val);
-		const double dxy = (double)((d1[c + w + 1] - d1[c - w + 1] - d1[c + w - 1] + d1[c - w - 1]) / 4);
-		const double dys = (double)((d2[c + w] - d2[c - w] - d0[c + w] + d0[c - w]) / 4);
-		const double dsx = (double)((d2[c + 1] - d2[c - 1] - d0[c + 1] + d0[c - 1]) / 4);
+		const double dxy = (double)((d1(c + w + 1) - d1(c - w + 1) - d1(c + w - 1) + d1(c - w - 1)) / 4);
+		const double dys = (double)((d2(c + w) - d2(c - w) - d0(c + w) + d0(c - w)) / 4);
+		const double dsx = (double)((d2(c + 1) - d2(c - 1) - d0(c + 1) + d0(c - 1)) / 4);
 		const double m[9] = {dxx, dxy, dsx, dxy, dyy, dys, dsx, dys, dss};
 		double inv[9];
 		if (!inverse3_fullpiv(m, inv)) pinv3_jacobi(m, inv);
@@ -144,17 +151,17 @@ __global__ void __launch_bounds__(128) k_refine(SiftPlan p, const int* raw, cons
 		nows = (int)((double)nows + round(offset[2]));
 	}
 	if (niter == p.calc_offset_depth) return;
-	const float* dn = base + plane_off_dog(od, nows);
 	const long long c = (long long)nowy * w + nowx;
+	auto dn = [&](long long i) { return dog(nows, i); };
 	double dextr = offset[0] * delta[0] + offset[1] * delta[1] + offset[2] * delta[2];
-	dextr = (double)dn[c] + dextr / 2;
+	dextr = (double)dn(c) + dextr / 2;
 	if (dextr < (double)p.contrast_thres) return;
 	// is_edge_response (:152-168) on the refined position
 	{
-		const float val = dn[c];
-		const float dxx = dn[c + 1] + dn[c - 1] - val - val;
-		const float dyy = dn[c + w] + dn[c - w] - val - val;
-		const float dxy = (dn[c + w + 1] + dn[c - w - 1] - dn[c + w - 1] - dn[c - w + 1]) / 4;
+		const float val = dn(c);
+		const float dxx = dn(c + 1) + dn(c - 1) - val - val;
+		const float dyy = dn(c + w) + dn(c - w) - val - val;
+		const float dxy = (dn(c + w + 1) + dn(c - w - 1) - dn(c + w - 1) - dn(c - w + 1)) / 4;
 		const float det = dxx * dyy - dxy * dxy;
 		if (det <= 0) return;
 		const float tr = dxx + dyy;

@@ -419,9 +419,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 
 		const int d = s - 1;                                 // DoG layer produced by this sigma
 		float* Dcur = Dr + (d % 3) * (GR * PG);
-		float* dog = ws + plane_off_dog(od, d);
-		const bool want_gauss = (s <= ns - 3);               // scales whose gradients are read (extrema.cc:75)
-		float* gauss = ws + plane_off_gauss(od, ns, want_gauss ? s : 1);
+		float* gauss = ws + plane_off_gauss(od, ns, s);      // the Gaussian stack is what reaches HBM (internal.hpp); |DoG| stays in LDS
 		float dcen[NPX];                                     // layer d-1 at this thread's pixels (scan centre)
 #pragma unroll
 		for (int k = 0; k < NPX; ++k) {
@@ -430,8 +428,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 			Dcur[lds0 + 4 * k * PG] = dv;
 			if (k < nvalid) {
 				const unsigned gi = gi0 + (unsigned)(4 * k) * (unsigned)od.w;
-				dog[gi] = dv;
-				if (want_gauss) gauss[gi] = cur;
+				gauss[gi] = cur;
 			}
 			prev[k] = cur;
 			dcen[k] = dprev[k]; dprev[k] = dv;
@@ -480,7 +477,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 //   row pass: thread = two adjacent columns of one of the two rows; the (sigma a, sigma b) pairs
 //     written by the column pass are read back as 64-bit LDS words and used as packed operands as
 //     they are.  All six Gaussian values of a pixel end up in ONE thread: |DoG| (dog.cc:126) is
-//     register arithmetic, the ten planes leave as 8-byte stores on coalesced rows.
+//     register arithmetic (it only feeds the scan), the six Gaussian planes leave as 8-byte stores on coalesced rows.
 //   scan: |DoG| rows go through a 4-row LDS ring.  Pixels passing the PRE_COLOR_THRES gate
 //     (extrema.cc:179) are compacted into an LDS queue and the 26-neighbour test (extrema.cc:181-207)
 //     runs one queue entry per thread, instead of every wave paying for its rarest lane.
@@ -489,23 +486,32 @@ constexpr int RW_OWN = OP_RW_OWN;     // columns owned by a band
 constexpr int RW_H = RW_OWN + 4;      // row-pass columns: x0 - 2 .. x0 + 241 (one ring column each side is used)
 constexpr int RW_QCAP = 1024;         // scan queue entries per row pair (overflow is handled in place)
 
-__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 w, f32x2 k) {      // (w.x * k.x, w.x * k.y)
-	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "s"(k)); return r;
+// wave64 inclusive add-scan on DPP (row_shr within the four rows of 16 lanes, then row_bcast:15 / :31 across rows);
+// call in wave-uniform control flow
+__device__ __forceinline__ int wave_scan_add_i(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+	return v;
 }
-__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 w, f32x2 k) {      // (w.y * k.x, w.y * k.y)
-	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "s"(k)); return r;
-}
-__device__ __forceinline__ f32x2 pk_mul(f32x2 w, f32x2 k) {         // (w.x * k.x, w.y * k.y)
-	f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(w), "s"(k)); return r;
-}
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte store at a 4-byte aligned address
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (a.x, b.x) / (a.y, b.y): one instruction each
+__device__ __forceinline__ f32x2 pk_lo(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_hi(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // (plain stores: non-temporal ones were measured 25 % slower here -- the rows start at arbitrary 4-byte
 // offsets, and L2 no longer merges the partial lines at wave and band seams before they reach HBM)
-__device__ __forceinline__ void store2(float* p, float a, float b) { *(f32x2u*)p = f32x2u{a, b}; }
-__device__ __forceinline__ void store1(float* p, float a) { *p = a; }
 
 // 26-neighbour test on the DoG ring (extrema.cc:181-207): slot = ring row of the centre
+#ifndef OP_PYR_EXPERIMENT
+#define OP_PYR_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
+#endif
 __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int slot, int L, int hc, float judge) {
+#if OP_PYR_EXPERIMENT == 6 || OP_PYR_EXPERIMENT == 7
+	return sD[0][L][hc] > judge * 1000.f;     // timing experiment: smaller ring, no real test
+#endif
 	const float center = sD[slot][L][hc];
 	const float cmp1 = center - judge, cmp2 = center + judge;
 	bool mx = true, mn = true;
@@ -525,13 +531,33 @@ __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int sl
 	return mx || mn;
 }
 
+#ifndef OP_PYR_EXPERIMENT
+#define OP_PYR_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
+#endif
+#if OP_PYR_EXPERIMENT == 9
+__device__ unsigned long long g_pyr_timers[12];   // 0-6 phases, 7 prologue, 8 lifetime, 9 workgroups, 10 steps
+#define PSTAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
 	__shared__ f32x2 sV[3][2][256];          // column-pass results [sigma pair][row of the pair][column]
 	__shared__ float sGrey[2][256];
-	__shared__ float sD[4][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
+#if OP_PYR_EXPERIMENT == 6
+#define OP_RING_ROWS 2
+#elif OP_PYR_EXPERIMENT == 7
+#define OP_RING_ROWS 1
+#else
+#define OP_RING_ROWS 4
+#endif
+	__shared__ float sD[OP_RING_ROWS][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
 	__shared__ unsigned short sQ[RW_QCAP];
 	__shared__ int sQn[2];
 	const int tid = threadIdx.x;
+#if OP_PYR_EXPERIMENT == 9
+	unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+	const unsigned long long tbegin = tlast;
+#endif
 	// work item; consecutive items (neighbouring bands share cache lines at their seams, neighbouring
 	// segments their halo rows) are handed to one XCD, i.e. one L2
 	const unsigned lin = blockIdx.x, per = gridDim.x >> 3;
@@ -561,8 +587,16 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 
 	// column-pass role: column x0 - 8 + tid, clamped
 	int xc = x0 - 8 + tid; xc = xc < 0 ? 0 : (xc > od.w - 1 ? od.w - 1 : xc);
-	const float* gcol = grey + xc;
-	auto grow = [&](int y) -> float { y = y < 0 ? 0 : (y > od.h - 1 ? od.h - 1 : y); return gcol[(unsigned)y * (unsigned)od.w]; };
+	// buffer addressing: the plane's descriptor and the row offset are uniform (SGPRs), the column a 32-bit per-thread
+	// byte offset -- no 64-bit VALU address arithmetic, and no address registers held across the loop
+	const unsigned plane_bytes = (unsigned)od.plane * 4u;
+	const __amdgpu_buffer_rsrc_t r_grey = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grey), 0, plane_bytes, 0x00020000);
+	const unsigned xc4 = (unsigned)xc * 4u;
+	auto grow = [&](int y) -> float {
+		y = y < 0 ? 0 : (y > od.h - 1 ? od.h - 1 : y);
+		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_grey, xc4, (unsigned)y * (unsigned)od.w * 4u, 0));
+	};
+	const __amdgpu_buffer_rsrc_t r_gau = __builtin_amdgcn_make_buffer_rsrc(ws + plane_off_gauss(od, 7, 1), 0, 6u * plane_bytes, 0x00020000);
 	f32x2 win[7];                                                 // grey rows r-6 .. r+7 of the current pair (r, r+1)
 #pragma unroll
 	for (int i = 0; i < 7; ++i) win[i] = f32x2{grow(y0 - 7 + 2 * i), grow(y0 - 6 + 2 * i)};
@@ -580,31 +614,45 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 #pragma unroll
 		for (int l = 0; l < 4; ++l) dprev[e][l] = 0.f;
 	if (tid < 2) sQn[tid] = 0;
+#if OP_PYR_EXPERIMENT == 9
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the window has landed: the prologue ends here
+#endif
+	PSTAMP(7);
 
 	for (int t = 0; t < nsteps; ++t) {
 		const int r = y0 - 1 + 2 * t;
 		const f32x2 nxt = f32x2{grow(r + 8), grow(r + 9)};        // the next pair's two new rows, in flight during this one
 		{	// ---- column pass: rows r (window elements 0..12) and r+1 (1..13)
+			// (the chains start from their first product: the reference's `tmp = 0; tmp += ...` (gaussian.hh:60-64) differs
+			// from it only in the sign of a zero sum, which no later stage can observe -- every consumer subtracts or compares)
 			f32x2 a0[3], a1[3];
+#define OP_WMUL(i, kp) ((((i) & 1) ? __builtin_shufflevector(win[(i) >> 1], win[(i) >> 1], 1, 1) : __builtin_shufflevector(win[(i) >> 1], win[(i) >> 1], 0, 0)) * (kp))
 #pragma unroll
-			for (int pl = 0; pl < 3; ++pl) { a0[pl] = f32x2{0.f, 0.f}; a1[pl] = f32x2{0.f, 0.f}; }
-#define OP_WMUL(i, kp) (((i) & 1) ? pk_mul_hi(win[(i) >> 1], kp) : pk_mul_lo(win[(i) >> 1], kp))
-#pragma unroll
-			for (int k = 0; k < 13; ++k) {
+			for (int k = 0; k < (OP_PYR_EXPERIMENT == 5 ? 1 : 13); ++k) {
 				const int d = k < 6 ? 6 - k : k - 6;
-				a0[1] = a0[1] + OP_WMUL(k, KP1[d]); a1[1] = a1[1] + OP_WMUL(k + 1, KP1[d]);
-				a0[2] = a0[2] + OP_WMUL(k, KP2[d]); a1[2] = a1[2] + OP_WMUL(k + 1, KP2[d]);
-				if (k >= 3 && k <= 9) {
+				if (k == 0) { a0[1] = OP_WMUL(k, KP1[d]); a1[1] = OP_WMUL(k + 1, KP1[d]); a0[2] = OP_WMUL(k, KP2[d]); a1[2] = OP_WMUL(k + 1, KP2[d]); }
+				else {
+					a0[1] = a0[1] + OP_WMUL(k, KP1[d]); a1[1] = a1[1] + OP_WMUL(k + 1, KP1[d]);
+					a0[2] = a0[2] + OP_WMUL(k, KP2[d]); a1[2] = a1[2] + OP_WMUL(k + 1, KP2[d]);
+				}
+				if (k == 3) { a0[0] = OP_WMUL(k, KP0[3]); a1[0] = OP_WMUL(k + 1, KP0[3]); }
+				else if (k > 3 && k <= 9) {
 					const int d0 = k < 6 ? 6 - k : k - 6;       // distance from the centre: 3..0..3
 					a0[0] = a0[0] + OP_WMUL(k, KP0[d0]); a1[0] = a1[0] + OP_WMUL(k + 1, KP0[d0]);
 				}
 			}
+			if (OP_PYR_EXPERIMENT == 5) { a0[0] = a0[1]; a1[0] = a1[1]; }
 #undef OP_WMUL
+#if OP_PYR_EXPERIMENT == 9
+			asm volatile("s_nop 0" :: "v"(a0[0]), "v"(a1[0]), "v"(a0[1]), "v"(a1[1]), "v"(a0[2]), "v"(a1[2]));
+#endif
+			PSTAMP(0);
 #pragma unroll
 			for (int pl = 0; pl < 3; ++pl) { sV[pl][0][tid] = a0[pl]; sV[pl][1][tid] = a1[pl]; }
 			sGrey[0][tid] = win[3].x; sGrey[1][tid] = win[3].y;
 		}
 		lds_barrier();
+		PSTAMP(1);
 
 		// ---- row pass + DoG for (row r + rr; columns h, h+1)
 		float dcur[2][6];
@@ -615,11 +663,11 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				f32x2 w[10];        // columns h+2 .. h+11: 16-byte aligned, so the window comes as five ds_read_b128
 #pragma unroll
 				for (int i = 0; i < 10; ++i) w[i] = sV[0][rr][h + 2 + i];
-				f32x2 a = f32x2{0.f, 0.f}, b = f32x2{0.f, 0.f};
+				f32x2 a = w[1] * KP0[3], b = w[2] * KP0[3];
 #pragma unroll
-				for (int k = 0; k < 7; ++k) {
+				for (int k = 1; k < (OP_PYR_EXPERIMENT == 4 ? 1 : 7); ++k) {
 					const int d = k < 3 ? 3 - k : k - 3;
-					a = a + pk_mul(w[k + 1], KP0[d]); b = b + pk_mul(w[k + 2], KP0[d]);
+					a = a + w[k + 1] * KP0[d]; b = b + w[k + 2] * KP0[d];
 				}
 				gA[0] = a; gB[0] = b;
 			}
@@ -628,38 +676,44 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				f32x2 w[14];
 #pragma unroll
 				for (int i = 0; i < 14; ++i) w[i] = sV[pl][rr][h + i];
-				f32x2 a = f32x2{0.f, 0.f}, b = f32x2{0.f, 0.f};
+				f32x2 a = w[0] * (pl == 1 ? KP1[6] : KP2[6]), b = w[1] * (pl == 1 ? KP1[6] : KP2[6]);
 #pragma unroll
-				for (int k = 0; k < 13; ++k) {
+				for (int k = 1; k < (OP_PYR_EXPERIMENT == 4 ? 1 : 13); ++k) {
 					const int d = k < 6 ? 6 - k : k - 6;
 					const f32x2 kp = pl == 1 ? KP1[d] : KP2[d];
-					a = a + pk_mul(w[k], kp); b = b + pk_mul(w[k + 1], kp);
+					a = a + w[k] * kp; b = b + w[k + 1] * kp;
 				}
 				gA[pl] = a; gB[pl] = b;
 			}
-			const float g0A = sGrey[rr][h + 6], g0B = sGrey[rr][h + 7];
-			// Gaussian stack of the two pixels: G[0] = grey (dog.cc:53), G[1..6]
-			const float GA[7] = {g0A, gA[0].x, gA[0].y, gA[1].x, gA[1].y, gA[2].x, gA[2].y};
-			const float GB[7] = {g0B, gB[0].x, gB[0].y, gB[1].x, gB[1].y, gB[2].x, gB[2].y};
+			// Gaussian stack of the two pixels as (pixel A, pixel B) pairs per scale: P[0] = grey (dog.cc:53), P[1..6].
+			// The accumulators hold (sigma a, sigma b) per pixel; one v_pk_mov_b32 per scale transposes them, and the
+			// pairs are then the operands of the packed |DoG| subtraction, of the ring writes and of the stores as they are.
+			f32x2 P[7];
+			P[0] = *(const f32x2*)&sGrey[rr][h + 6];
 #pragma unroll
-			for (int l = 0; l < 6; ++l) { dcur[0][l] = fabsf(GA[l] - GA[l + 1]); dcur[1][l] = fabsf(GB[l] - GB[l + 1]); }   // dog.cc:126
-			const int slot = (2 * t + rr) & 3;
+			for (int pl = 0; pl < 3; ++pl) { P[2 * pl + 1] = pk_lo(gA[pl], gB[pl]); P[2 * pl + 2] = pk_hi(gA[pl], gB[pl]); }
+			f32x2 D[6];
 #pragma unroll
-			for (int l = 0; l < 6; ++l) *(f32x2*)&sD[slot][l][h] = f32x2{dcur[0][l], dcur[1][l]};
-			if (st0 && y >= y0 && y < y0 + rows_own) {
-				const unsigned gi = (unsigned)y * (unsigned)od.w + (unsigned)x;
-				float* dog0 = ws + plane_off_dog(od, 0) + gi;
-				float* gau1 = ws + plane_off_gauss(od, 7, 1) + gi;
+			for (int l = 0; l < 6; ++l) {                         // dog.cc:126
+				const f32x2 d = P[l] - P[l + 1];
+				D[l] = f32x2{fabsf(d.x), fabsf(d.y)};
+				dcur[0][l] = D[l].x; dcur[1][l] = D[l].y;
+			}
+			const int slot = (2 * t + rr) & (OP_RING_ROWS - 1);
+#if OP_PYR_EXPERIMENT == 9
+			asm volatile("s_nop 0" :: "v"(dcur[0][0]), "v"(dcur[1][5]), "v"(dcur[0][3]), "v"(dcur[1][2]));
+#endif
+			PSTAMP(2);
+#pragma unroll
+			for (int l = 0; l < 6; ++l) *(f32x2*)&sD[slot][l][h] = D[l];
+			if (OP_PYR_EXPERIMENT != 3 && st0 && y >= y0 && y < y0 + rows_own) {
+				const unsigned bo = ((unsigned)y * (unsigned)od.w + (unsigned)x) * 4u;
 				if (st1) {
 #pragma unroll
-					for (int l = 0; l < 6; ++l) store2(dog0 + (long long)l * od.plane, dcur[0][l], dcur[1][l]);
-#pragma unroll
-					for (int s = 1; s <= 4; ++s) store2(gau1 + (long long)(s - 1) * od.plane, GA[s], GB[s]);
+					for (int s = 1; s <= 6; ++s) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, P[s]), r_gau, bo, (unsigned)(s - 1) * plane_bytes, 0);
 				} else {
 #pragma unroll
-					for (int l = 0; l < 6; ++l) store1(dog0 + (long long)l * od.plane, dcur[0][l]);
-#pragma unroll
-					for (int s = 1; s <= 4; ++s) store1(gau1 + (long long)(s - 1) * od.plane, GA[s]);
+					for (int s = 1; s <= 6; ++s) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, P[s].x), r_gau, bo, (unsigned)(s - 1) * plane_bytes, 0);
 				}
 			}
 		} else {
@@ -669,10 +723,14 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				for (int l = 0; l < 6; ++l) dcur[e][l] = 0.f;
 		}
 
+		PSTAMP(3);
 		// ---- gate: rr == 0 scans its current row r (row r+1 is written by the other half in this
 		// pair), rr == 1 scans the row it produced in the previous pair (r-1)
 		const int ysc = rr == 0 ? y : y - 2;
 		unsigned mine = 0;                                        // candidates that did not fit the queue
+#if OP_PYR_EXPERIMENT == 1 || OP_PYR_EXPERIMENT == 2
+		if (false)
+#endif
 		{
 			unsigned mask = 0;
 			if (ysc >= y0 && ysc < y0 + rows_own && ysc >= 1 && ysc <= od.h - 2) {
@@ -684,8 +742,18 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 						if ((e == 0 ? sc0 : sc1) && !(c < p.pre_color_thres)) mask |= 1u << (e * 4 + l - 1);   // extrema.cc:179
 					}
 			}
+			// queue slots: one wave prefix sum (DPP) and ONE LDS atomic per wave -- a per-lane atomicAdd with lane-varying
+			// operands is serialised by the compiler into a readlane loop over the active lanes
+			const int cnt = __popc(mask);
+			const int incl = wave_scan_add_i(cnt);
+			const int wtot = __builtin_amdgcn_readlane(incl, 63);
+			int wbase = 0;
+			if (wtot) {
+				if ((tid & 63) == 63) wbase = atomicAdd(&sQn[t & 1], wtot);
+				wbase = __builtin_amdgcn_readlane(wbase, 63);
+			}
 			if (mask) {
-				int base = atomicAdd(&sQn[t & 1], __popc(mask));
+				int base = wbase + incl - cnt;
 				for (unsigned m = mask; m; m &= m - 1) {
 					const int b = __ffs(m) - 1;
 					if (base < RW_QCAP) sQ[base] = (unsigned short)((h + (b >> 2)) | (((b & 3) + 1) << 8) | (rr << 11));
@@ -698,10 +766,17 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 		for (int e = 0; e < 2; ++e)
 #pragma unroll
 			for (int l = 0; l < 4; ++l) dprev[e][l] = dcur[e][l + 1];
+		PSTAMP(4);
+#if OP_PYR_EXPERIMENT != 2
 		lds_barrier();
+#endif
+		PSTAMP(5);
 
 		// ---- scan the queue: one entry per thread
 		if (tid == 0) sQn[(t + 1) & 1] = 0;
+#if OP_PYR_EXPERIMENT == 1 || OP_PYR_EXPERIMENT == 2
+		if (false)
+#endif
 		{
 			int n = sQn[t & 1]; n = n > RW_QCAP ? RW_QCAP : n;
 			for (int i = tid; i < n; i += 256) {
@@ -726,8 +801,24 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 #pragma unroll
 		for (int i = 0; i < 6; ++i) win[i] = win[i + 1];
 		win[6] = nxt;
+		PSTAMP(6);
 	}
+#if OP_PYR_EXPERIMENT == 9
+	if (tid == 0) {
+		for (int k = 0; k < 8; ++k) atomicAdd(&g_pyr_timers[k], tacc[k]);
+		atomicAdd(&g_pyr_timers[8], clock64() - tbegin); atomicAdd(&g_pyr_timers[9], 1ULL); atomicAdd(&g_pyr_timers[10], (unsigned long long)nsteps);
+	}
+#endif
 }
+#if OP_PYR_EXPERIMENT == 9
+}	// namespace
+extern "C" int op_debug_pyr_timers(unsigned long long* out) {
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pyr_timers), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+	unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_pyr_timers), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
 
 // debug / staged dump: GaussianPyramid::cal_mag_ort (feature/dog.cc:60-94) of one Gaussian plane
 __global__ void __launch_bounds__(256) k_magort_plane(SiftPlan p, int img, int o, int s, float* mag, float* ort) {

@@ -581,7 +581,15 @@ int op_sift_dump_plane(op_ctx* ctx, const op_sift_dump* d, int kind, int oct, in
 	const OctDesc& o = p.oct[oct];
 	long long off;
 	if (kind == 5) off = plane_off_grey(o);
-	else if (kind == 1 && s >= 0 && s <= p.nscale - 2) off = plane_off_dog(o, s);
+	else if (kind == 1 && s >= 0 && s <= p.nscale - 2) {
+		// DoG planes are never materialised by the product path (internal.hpp); the dump evaluates
+		// dog[s] = |G[s] - G[s+1]| (feature/dog.cc:126) on the two Gaussian planes, one fp32 subtraction per pixel
+		std::vector<float> nxt((size_t)o.plane);
+		HIPCHK(hipMemcpy(out, p.ws + plane_off_gauss(o, p.nscale, s), sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(nxt.data(), p.ws + plane_off_gauss(o, p.nscale, s + 1), sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost));
+		for (long long i = 0; i < o.plane; ++i) out[i] = std::fabs(out[i] - nxt[i]);
+		return OP_OK;
+	}
 	else if ((kind == 2 || kind == 3) && s >= 1 && s <= p.nscale - 3) {
 		// mag / ort planes are never materialised by the product path; the dump computes them
 		float* tmp = nullptr;
@@ -593,7 +601,7 @@ int op_sift_dump_plane(op_ctx* ctx, const op_sift_dump* d, int kind, int oct, in
 		if (e != hipSuccess) OP_FAIL(OP_ERR_HIP, std::string("op_sift_dump_plane: ") + hipGetErrorString(e));
 		return OP_OK;
 	}
-	else if (kind == 6 && s >= 1 && s <= p.nscale - 3) off = plane_off_gauss(o, p.nscale, s);
+	else if (kind == 6 && s >= 1 && s <= p.nscale - 1) off = plane_off_gauss(o, p.nscale, s);
 	else OP_FAIL(OP_ERR_INVALID, "bad plane kind/scale");
 	HIPCHK(hipMemcpy(out, p.ws + off, sizeof(float) * (size_t)o.plane, hipMemcpyDeviceToHost));
 	return OP_OK;
