@@ -150,7 +150,9 @@ struct KeyPoint {
 };
 
 #define OP_RW_OWN 240     // k_pyramid_rows: columns owned by a band
-#define OP_RW_SEG 16      // rows of a segment
+#ifndef OP_RW_SEG
+#define OP_RW_SEG 24      // rows of a segment
+#endif
 #define OP_PYR_TW 64
 #ifndef OP_PYR_TH
 #define OP_PYR_TH 16

@@ -498,6 +498,11 @@ __device__ __forceinline__ int wave_scan_add_i(int v) {
 	return v;
 }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// mask = 2 * mask + !(c < thr): one comparison into vcc, one add-with-carry
+__device__ __forceinline__ unsigned gate_bit(unsigned m, float c, float thr) {
+	asm("v_cmp_nlt_f32_e64 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(c), "s"(thr) : "vcc");
+	return m;
+}
 // (a.x, b.x) / (a.y, b.y): one instruction each
 __device__ __forceinline__ f32x2 pk_lo(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_hi(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -508,13 +513,18 @@ __device__ __forceinline__ f32x2 pk_hi(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mo
 #ifndef OP_PYR_EXPERIMENT
 #define OP_PYR_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
 #endif
+__device__ __forceinline__ float max3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// The reference clears `max` on any neighbour v >= center - judge and `min` on any v <= center + judge: with the largest
+// and the smallest of the 26 neighbours (v_max3 / v_min3 skip NaNs like the element-wise comparisons do) that is two
+// comparisons, written negated so that a NaN on either side leaves the flag set as the reference's loop does.
 __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int slot, int L, int hc, float judge) {
 #if OP_PYR_EXPERIMENT == 6 || OP_PYR_EXPERIMENT == 7
 	return sD[0][L][hc] > judge * 1000.f;     // timing experiment: smaller ring, no real test
 #endif
 	const float center = sD[slot][L][hc];
 	const float cmp1 = center - judge, cmp2 = center + judge;
-	bool mx = true, mn = true;
+	float v[26]; int n = 0;
 #pragma unroll
 	for (int di = -1; di <= 1; ++di) {
 		const int sl = (slot + di) & 3;
@@ -523,17 +533,16 @@ __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int sl
 #pragma unroll
 			for (int dj = -1; dj <= 1; ++dj) {
 				if (di == 0 && dl == 0 && dj == 0) continue;
-				const float v = sD[sl][L + dl][hc + dj];
-				if (v >= cmp1) mx = false;
-				if (v <= cmp2) mn = false;
+				v[n++] = sD[sl][L + dl][hc + dj];
 			}
 	}
-	return mx || mn;
+	float mx = max3f(v[0], v[1], v[2]), mn = min3f(v[0], v[1], v[2]);
+#pragma unroll
+	for (int i = 3; i + 1 < 26; i += 2) { mx = max3f(mx, v[i], v[i + 1]); mn = min3f(mn, v[i], v[i + 1]); }
+	mx = max3f(mx, v[25], v[25]); mn = min3f(mn, v[25], v[25]);
+	return !(mx >= cmp1) || !(mn <= cmp2);
 }
 
-#ifndef OP_PYR_EXPERIMENT
-#define OP_PYR_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
-#endif
 #if OP_PYR_EXPERIMENT == 9
 __device__ unsigned long long g_pyr_timers[12];   // 0-6 phases, 7 prologue, 8 lifetime, 9 workgroups, 10 steps
 #define PSTAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
@@ -608,11 +617,8 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 	const bool own = j >= 1 && j <= RW_OWN / 2;                   // both columns owned by this band
 	const bool st0 = own && x < od.w, st1 = own && x + 1 < od.w;
 	const bool sc0 = st0 && x >= 1 && x <= od.w - 2, sc1 = st1 && x + 1 <= od.w - 2;   // extrema.cc:212
-	float dprev[2][4];                                            // this thread's |DoG| layers 1..4 of the previous pair
-#pragma unroll
-	for (int e = 0; e < 2; ++e)
-#pragma unroll
-		for (int l = 0; l < 4; ++l) dprev[e][l] = 0.f;
+	const unsigned allow = (sc0 ? 0x0Fu : 0u) | (sc1 ? 0xF0u : 0u);
+	unsigned pm = 0;                                              // rr == 1: the gate mask of the row produced in the previous pair
 	if (tid < 2) sQn[tid] = 0;
 #if OP_PYR_EXPERIMENT == 9
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the window has landed: the prologue ends here
@@ -726,22 +732,24 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 		PSTAMP(3);
 		// ---- gate: rr == 0 scans its current row r (row r+1 is written by the other half in this
 		// pair), rr == 1 scans the row it produced in the previous pair (r-1)
-		const int ysc = rr == 0 ? y : y - 2;
+		// Every thread gates the 8 candidates of ITS row (2 columns x DoG layers 1..4, extrema.cc:179) into a bit mask:
+		// v_cmp + v_addc (mask = 2 mask + pass) per candidate.  The rr == 0 waves queue their mask at once (row r: its
+		// lower neighbour r+1 is being written by the other half in this very pair), the rr == 1 waves queue the mask they
+		// made in the previous pair (row r-1) and keep the new one -- a row's validity is a wave-uniform test.
 		unsigned mine = 0;                                        // candidates that did not fit the queue
+		const int rru = __builtin_amdgcn_readfirstlane(rr);
+		const int ysc = rru == 0 ? r : r - 1;
 #if OP_PYR_EXPERIMENT == 1 || OP_PYR_EXPERIMENT == 2
 		if (false)
 #endif
 		{
-			unsigned mask = 0;
-			if (ysc >= y0 && ysc < y0 + rows_own && ysc >= 1 && ysc <= od.h - 2) {
+			unsigned cm = 0;
 #pragma unroll
-				for (int e = 0; e < 2; ++e)
-#pragma unroll
-					for (int l = 1; l <= 4; ++l) {
-						const float c = rr == 0 ? dcur[e][l] : dprev[e][l - 1];
-						if ((e == 0 ? sc0 : sc1) && !(c < p.pre_color_thres)) mask |= 1u << (e * 4 + l - 1);   // extrema.cc:179
-					}
-			}
+			for (int b = 7; b >= 0; --b) cm = gate_bit(cm, dcur[b >> 2][(b & 3) + 1], p.pre_color_thres);
+			cm &= allow;
+			unsigned mask;
+			if (rru == 0) mask = cm; else { mask = pm; pm = cm; }
+			if (!(ysc >= y0 && ysc < y0 + rows_own && ysc >= 1 && ysc <= od.h - 2)) mask = 0;     // extrema.cc:212
 			// queue slots: one wave prefix sum (DPP) and ONE LDS atomic per wave -- a per-lane atomicAdd with lane-varying
 			// operands is serialised by the compiler into a readlane loop over the active lanes
 			const int cnt = __popc(mask);
@@ -762,10 +770,6 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				}
 			}
 		}
-#pragma unroll
-		for (int e = 0; e < 2; ++e)
-#pragma unroll
-			for (int l = 0; l < 4; ++l) dprev[e][l] = dcur[e][l + 1];
 		PSTAMP(4);
 #if OP_PYR_EXPERIMENT != 2
 		lds_barrier();

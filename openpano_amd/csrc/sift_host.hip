@@ -173,9 +173,9 @@ int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
 		for (int s = 1; s < 7 && p.rows_ok; ++s) if (p.kcenter[s] != shipped[s - 1]) p.rows_ok = 0;
 		if (p.rows_ok) {
 			// work items of k_pyramid_rows: bands of OP_RW_OWN columns x segments of OP_RW_SEG rows.
-			// Short segments win although each re-reads 14 halo rows and adds a row pair of column-pass
-			// work: measured on config 4, 16 rows 0.52 ms, 32 rows 0.57, 64 rows 0.59 (ramp-up and
-			// tail cost more than a workgroup lifetime, and the lifetime grows with the segment).
+			// Every segment re-reads 14 halo rows and adds three rows of redundant passes; long segments pay in ramp-up
+			// and tail (a workgroup's lifetime grows with the segment).  Measured on config 4 with the kernel as it is
+			// now (VALU-bound: 6 planes out): 16 rows 0.392 ms, 24 rows 0.382, 32 rows 0.394.
 			p.rw_items = 0;
 			for (int i = 0; i < p.noct; ++i) {
 				OctDesc& o = p.oct[i];
