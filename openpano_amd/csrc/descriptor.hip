@@ -67,11 +67,15 @@ __device__ __forceinline__ int wave_max_i(int v) {                        // v >
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
+// popcount of the mask bits BELOW this lane: v_mbcnt_lo + v_mbcnt_hi, no explicit lane mask
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+	return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
 		const long long* img_offset, long long cap, float* desc, double* coor, double* real) {
 	__shared__ DescLds S;
 	const int lane = threadIdx.x;
-	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 	const float pi2 = (float)(2 * 3.14159265358979323846);
 	const float nbin_per_rad = 8 / pi2;
 	S.mask[2 * lane] = 0ULL; S.mask[2 * lane + 1] = 0ULL;
@@ -225,9 +229,11 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				const int incl = wave_scan_add(p0 + p1);                   // inclusive wave scan of the per-lane pair sizes
 				const int ex = incl - (p0 + p1);
 				S.off[2 * lane] = (unsigned short)ex; S.off[2 * lane + 1] = (unsigned short)(ex + p0);
-				// zero the padding slots (at most 3 per list): +0.0f leaves an fp32 sum of non-negative terms unchanged
-				for (int e = c0; e < p0; ++e) S.sorted[ex + e] = 0.f;
-				for (int e = c1; e < p1; ++e) S.sorted[ex + p0 + e] = 0.f;
+				// zero the padding slots (at most 3 per list, all inside the list's last float4): +0.0f leaves an fp32 sum of
+				// non-negative terms unchanged.  The whole last float4 is cleared with one 16-byte write; the scatter below
+				// (after the barrier) overwrites the slots that hold values.
+				if (p0) *(f32x4*)&S.sorted[ex + p0 - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+				if (p1) *(f32x4*)&S.sorted[ex + p0 + p1 - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
 			}
 			__syncthreads();
 #pragma unroll
@@ -235,8 +241,8 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				if (cb[u] >= 0) {
 					const int hn = (hq + 1) & 7;
 					const unsigned long long mp = S.mask[cb[u] + ((hq + 7) & 7)], m0 = S.mask[cb[u] + hq], mn = S.mask[cb[u] + hn];
-					S.sorted[S.off[cb[u] + hq] + __popcll((m0 | mp) & lt_mask)] = vA[u];
-					S.sorted[S.off[cb[u] + hn] + __popcll((mn | m0) & lt_mask)] = vB[u];
+					S.sorted[S.off[cb[u] + hq] + rank_below(m0 | mp)] = vA[u];
+					S.sorted[S.off[cb[u] + hn] + rank_below(mn | m0)] = vB[u];
 				}
 			__syncthreads();
 			// phase 3: ordered accumulation.  Lane L owns bins L and L + 64 (cells 8 apart: when one is
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			if (!cols) { qy += 64; while (qy >= side) { qy -= side; ++qx; } }
 			const unsigned long long mask = __ballot(ok);
 			if (ok) {
-				const int qi = (qhead + qn + __popcll(mask & lt_mask)) & (QCAP - 1);
+				const int qi = (qhead + qn + rank_below(mask)) & (QCAP - 1);
 				S.q_gi[qi] = gi; S.q_xr[qi] = x_rot; S.q_yr[qi] = y_rot;
 			}
 			qn += __popcll(mask);

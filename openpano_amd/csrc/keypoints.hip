@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 	const int img = blockIdx.y;
 	const int count = refined_count[img];
 	const int lane = threadIdx.x;
-	const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 	const float* base = p.ws + (long long)img * p.ws_stride;
 	const float halfipi = (float)(0.5f / 3.14159265358979323846);
 	if (lane < ORI_BINS) s_mask[lane] = 0ULL;
@@ -325,9 +324,14 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 			const int c = __popcll(m), pc = (c + 3) & ~3;   // list length, rounded up to whole float4s
 			const int ex = ori_scan_add(pc) - pc;            // exclusive wave scan of the padded bin sizes
 			s_off[lane] = (unsigned short)ex;
-			for (int e = c; e < pc; ++e) s_sorted[ex + e] = 0.f;       // +0.0f padding leaves the non-negative fp32 sums unchanged
+			// +0.0f padding leaves the non-negative fp32 sums unchanged: the list's last float4 is cleared with one 16-byte
+			// write, the scatter below (after the barrier) overwrites the slots that hold values
+			if (pc) *(f32x4*)&s_sorted[ex + pc - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
 			__syncthreads();
-			if (bin >= 0) s_sorted[s_off[bin] + __popcll(s_mask[bin] & lt_mask)] = val;
+			if (bin >= 0) {
+				const unsigned long long bm = s_mask[bin];
+				s_sorted[s_off[bin] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u))] = val;
+			}
 			__syncthreads();
 			{
 				const f32x4* l = (const f32x4*)&s_sorted[ex];
