@@ -125,6 +125,11 @@ int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* c
  * the all-gathered descriptors of every rank's images to the matcher this way */
 int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev,
 		const int* counts, int n, op_features** out);
+/* the same without the copy: the table ADOPTS the caller's device buffers (total x 128 fp32, total x 2 fp64, images
+ * back to back), which must stay valid and unchanged until op_features_free -- the exchange step of the multi-GPU
+ * path receives every rank's features straight into such a table and hands it to the matcher as it is */
+int op_features_adopt_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev,
+		const int* counts, int n, op_features** out);
 void op_features_free(op_features* f);
 
 /* Staged single-image run keeping every intermediate (the debug commands raw_extrema /
@@ -198,14 +203,22 @@ int op_group_create(const int* devices, int ndev, op_group** out);   /* a device
 void op_group_destroy(op_group* g);
 int op_group_size(const op_group* g);
 op_ctx* op_group_ctx(op_group* g, int k);                             /* context k; context 0 holds gathered results */
-/* StitcherBase::calc_feature sharded by image: image i runs on context i % ndev; the features are
- * gathered (device-to-device over xGMI) into ONE op_features on context 0.  Host images only, or
- * device images resident on the device of the context that owns them. */
+/* StitcherBase::calc_feature sharded by image: contiguous blocks of n / ndev images per context; the features are
+ * all-gathered device-to-device over xGMI (every device pulls the other devices' slices over its own links) -- the
+ * returned op_features is the table on context 0 and carries its replicas on the other devices.  Host images only,
+ * or device images resident on the device of the context that owns them. */
 int op_sift_batch_multi(op_group* g, const op_config* cfg, const op_image* imgs, int n, op_features** out);
-/* Stitcher::pairwise_match sharded by pair: the feature table is replicated to every device (the
- * descriptor all-gather of SURVEY 8(e).2), the pair list is dealt balanced by K_i * K_j, the per-pair
- * lists come back in the order of `pairs`. */
+/* Stitcher::pairwise_match sharded by pair: every device uses its replica of the table (made by op_sift_batch_multi, or
+ * pulled from f's device on first use), the pair list is dealt balanced by K_i * K_j, each device keeps the lists of
+ * its pairs resident; counts / lists read back in the order of `pairs`. */
 int op_match_pairs_multi(op_group* g, const op_config* cfg, const op_features* f, const int* pairs, int npairs, op_matches** out);
+/* TransformEstimation for the same job (stitch/stitcher.cc:66-94 inside the pair loop): every device estimates the pairs it
+ * matched -- their match lists are resident there -- with the seeds op_ransac_pairs would give them; the result is in the
+ * order of `pairs`.  m from op_match_pairs (one device) or wrapped host lists runs on context 0. */
+struct op_ransac_result;
+int op_ransac_pairs_multi(op_group* g, const op_config* cfg, const op_features* f, const op_matches* m,
+		const int* pairs, int npairs, const int* shapes_wh, const uint32_t* seeds, uint32_t base_seed,
+		struct op_ransac_result** out);
 
 /* =====================================================================================
  * RANSAC -- replaces TransformEstimation(...).get_transform(MatchInfo*)

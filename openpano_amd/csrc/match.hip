@@ -41,19 +41,38 @@ struct op_matches {
 	mutable std::vector<int> h_idx;    // host mirror of d_idx, fetched on first use
 	mutable bool host_valid = false;
 	mutable std::mutex mu;
-	~op_matches() { if (d_idx) { hipSetDevice(device); pool_free(d_idx); } }
+	// multi.hip: a job matched on several devices keeps its per-device results (parts[k] holds the pairs
+	// part_index[k][0..] of the job's pair list, resident on device k) so that RANSAC follows the same deal without
+	// a round trip through the host; the flat host list is assembled from the parts on first use
+	std::vector<op_matches*> parts;
+	std::vector<std::vector<int>> part_index;
+	~op_matches() {
+		if (d_idx) { hipSetDevice(device); pool_free(d_idx); }
+		for (op_matches* p : parts) delete p;
+	}
 };
 
 int op_matches_num_pairs(const op_matches* m) { return m->npairs; }
 const std::vector<int>& op_matches_counts(const op_matches* m) { return m->count; }
 const std::vector<int64_t>& op_matches_offsets(const op_matches* m) { return m->offset; }
 const std::vector<int>& op_matches_limits(const op_matches* m) { return m->lim; }
+const std::vector<op_matches*>& op_matches_parts(const op_matches* m) { return m->parts; }
+const std::vector<std::vector<int>>& op_matches_part_index(const op_matches* m) { return m->part_index; }
 // flat host list (total x 2), fetched from the device once; nullptr + error set on failure
 const int* op_matches_host(const op_matches* m) {
 	std::lock_guard<std::mutex> lk(m->mu);
 	if (m->host_valid) return m->h_idx.data();
 	m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
-	if (m->total && m->d_idx) {
+	if (!m->parts.empty()) {
+		for (size_t k = 0; k < m->parts.size(); ++k) {
+			const int* src = op_matches_host(m->parts[k]);
+			if (!src) return nullptr;
+			for (size_t q = 0; q < m->part_index[k].size(); ++q) {
+				const int c = m->parts[k]->count[q];
+				if (c) std::memcpy(m->h_idx.data() + 2 * m->offset[m->part_index[k][q]], src + 2 * m->parts[k]->offset[q], sizeof(int) * 2 * (size_t)c);
+			}
+		}
+	} else if (m->total && m->d_idx) {
 		hipError_t e = hipSetDevice(m->device);
 		if (e == hipSuccess) e = hipMemcpyAsync(m->h_idx.data(), m->d_idx, sizeof(int) * 2 * (size_t)m->total, hipMemcpyDeviceToHost, m->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
@@ -62,10 +81,15 @@ const int* op_matches_host(const op_matches* m) {
 	m->host_valid = true;
 	return m->h_idx.data();
 }
-// device list on `device` if the matches live there (else nullptr: the caller uploads the host list)
-const int* op_matches_device(const op_matches* m, int device) { return (m->d_idx && m->device == device) ? m->d_idx : nullptr; }
-// multi.hip: parts[k] holds the pairs index[k][0..] of the job's pair list -> one op_matches in job order.
-// The parts live on different devices; the merged object is host-resident (RANSAC uploads what it needs).
+// device list on `device` if the matches live there (else nullptr: the caller uploads the host list).  The list's
+// producer (the per-pair sort) is only ORDERED on the stream it was made on: a consumer on another stream waits for it.
+const int* op_matches_device(const op_matches* m, int device, hipStream_t consumer) {
+	if (!m->d_idx || m->device != device) return nullptr;
+	if (m->stream != consumer && hipStreamSynchronize(m->stream) != hipSuccess) return nullptr;
+	return m->d_idx;
+}
+// multi.hip: parts[k] holds the pairs index[k][0..] of the job's pair list -> one op_matches in job order that OWNS
+// the parts (they stay on their devices); only counts are merged here
 op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::vector<int>>& index, int npairs) {
 	op_matches* m = new op_matches;
 	m->npairs = npairs; m->count.assign(npairs, 0); m->offset.assign(npairs + 1, 0); m->lim.assign((size_t)npairs * 2, 0);
@@ -76,16 +100,8 @@ op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::ve
 		}
 	for (int p = 0; p < npairs; ++p) m->offset[p + 1] = m->offset[p] + m->count[p];
 	m->total = m->offset[npairs];
-	m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
-	for (size_t k = 0; k < index.size(); ++k) {
-		const int* src = op_matches_host(parts[k]);
-		if (!src) { delete m; return nullptr; }
-		for (size_t q = 0; q < index[k].size(); ++q) {
-			const int c = parts[k]->count[q];
-			if (c) std::memcpy(m->h_idx.data() + 2 * m->offset[index[k][q]], src + 2 * parts[k]->offset[q], sizeof(int) * 2 * (size_t)c);
-		}
-	}
-	m->host_valid = true;
+	m->parts.assign(parts, parts + index.size());
+	m->part_index = index;
 	return m;
 }
 

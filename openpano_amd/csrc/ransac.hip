@@ -34,7 +34,7 @@ const std::vector<int>& op_matches_counts(const op_matches* m);
 const std::vector<int64_t>& op_matches_offsets(const op_matches* m);
 const std::vector<int>& op_matches_limits(const op_matches* m);
 const int* op_matches_host(const op_matches* m);
-const int* op_matches_device(const op_matches* m, int device);
+const int* op_matches_device(const op_matches* m, int device, hipStream_t consumer);
 
 using opransac::P2;
 
@@ -46,6 +46,15 @@ struct op_ransac_result {
 	};
 	std::vector<Item> items;
 };
+
+// multi.hip: parts[k] holds the results of the pairs index[k][0..] -> one result in job order (parts are consumed)
+op_ransac_result* op_ransac_merge(op_ransac_result* const* parts, const std::vector<std::vector<int>>& index, int npairs) {
+	op_ransac_result* r = new op_ransac_result;
+	r->items.resize(npairs);
+	for (size_t k = 0; k < index.size(); ++k)
+		for (size_t q = 0; q < index[k].size(); ++q) r->items[index[k][q]] = std::move(parts[k]->items[q]);
+	return r;
+}
 
 namespace {
 
@@ -592,7 +601,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	// the match lists if they only exist on the host] go up in one copy, [winner | its sample | gathered points] come
 	// back in one copy.  Samples, generator states and hypothesis counts exist per LIVE pair only.
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-	const int* d_midx_resident = op_matches_device(mt, ctx->device);
+	const int* d_midx_resident = op_matches_device(mt, ctx->device, st);
 	const bool upload_lists = !d_midx_resident && mtotal > 0;
 	const size_t u_pa = 0, u_seeds = al(u_pa + sizeof(PairArgs) * npairs), u_active = al(u_seeds + sizeof(unsigned) * npairs),
 			u_lists = al(u_active + sizeof(int) * nactive), up_bytes = al(u_lists + (upload_lists ? sizeof(int) * 2 * (size_t)mtotal : 0));

@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 size_t pyramid_lds_bytes(int halo);
 
@@ -75,7 +77,11 @@ struct op_features {
 	double* coor = nullptr;            // device, total x 2 (centred original-image pixels)
 	double* real = nullptr;            // device, total x 2 (real_coor in [0,1)); null when built from host/device arrays
 	bool has_desc = true;              // false: coordinates only (RANSAC-only use)
+	bool owns = true;                  // false: desc / coor belong to the caller (op_features_adopt_device)
 	int device = 0;
+	// multi.hip: the same table on the other devices of an op_group (index = context of the group; [0] unused),
+	// filled by the all-gather of op_sift_batch_multi / the first op_match_pairs_multi and owned by this object
+	std::vector<op_features*> replicas;
 	// host mirror of coor, fetched the first time a host stage asks for it (the acceptance epilogue of
 	// op_ransac_pairs walks every keypoint of both images; features are immutable, so one copy serves every call)
 	mutable std::vector<double> h_coor; mutable bool h_coor_valid = false; mutable std::mutex h_mu;
@@ -466,6 +472,18 @@ int op_features_from_host(op_ctx* ctx, const float* const* desc, const double* c
 	return OP_OK;
 }
 
+int op_features_adopt_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev, const int* counts, int n, op_features** out) {
+	if (!ctx || !desc_dev || !coor_dev || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_adopt_device: bad argument");
+	op_features* f = new op_features;
+	f->n = n; f->counts.assign(counts, counts + n); f->offsets.assign(n + 1, 0); f->device = ctx->device; f->owns = false;
+	int64_t total = 0;
+	for (int i = 0; i < n; ++i) { if (counts[i] < 0) { delete f; OP_FAIL(OP_ERR_INVALID, "negative count"); } f->offsets[i] = total; total += counts[i]; }
+	f->offsets[n] = total;
+	f->desc = const_cast<float*>(desc_dev); f->coor = const_cast<double*>(coor_dev);
+	*out = f;
+	return OP_OK;
+}
+
 int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* coor_dev, const int* counts, int n, op_features** out) {
 	if (!ctx || !desc_dev || !counts || n <= 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_features_from_device: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
@@ -487,6 +505,7 @@ int op_features_from_device(op_ctx* ctx, const float* desc_dev, const double* co
 
 }	// extern "C"
 
+extern "C" void op_features_free(op_features* f);
 // device-to-device copy between two contexts' devices, ordered on dst's stream (xGMI peer copy when the
 // devices differ; multi.hip enables direct peer access where the hardware allows it)
 static hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
@@ -495,33 +514,56 @@ static hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_
 	return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
 }
 
-// multi.hip: image i of the job lives in parts[i % nparts] at local index i / nparts -> one table on dst's device
-int op_features_gather_sharded(op_ctx* dst, op_features* const* parts, int nparts, int n, op_features** out) {
-	HIPCHK(hipSetDevice(dst->device));
-	op_features* f = new op_features;
-	f->n = n; f->counts.assign(n, 0); f->offsets.assign(n + 1, 0); f->device = dst->device;
-	int64_t total = 0;
-	for (int i = 0; i < n; ++i) { f->counts[i] = parts[i % nparts]->counts[i / nparts]; f->offsets[i] = total; total += f->counts[i]; }
-	f->offsets[n] = total;
+// multi.hip, the all-gather of SURVEY 8(e).2 inside one process: part k holds the images [start[k], start[k+1]) of the
+// job (contiguous blocks); EVERY device of the group gets the whole image-indexed table, each pulling the other
+// devices' slices over its own xGMI links (one host thread per destination, all pairs of devices busy at once; no
+// device relays another one's data).  tables[k] lands on ctxs[k]'s device.
+int op_features_allgather_blocks(op_ctx* const* ctxs, int nctx, op_features* const* parts, const int* start, int n, op_features** tables) {
+	std::vector<int> counts(n);
+	std::vector<int64_t> offsets(n + 1, 0);
+	for (int k = 0; k < nctx; ++k)
+		for (int i = start[k]; i < start[k + 1]; ++i) counts[i] = parts[k]->counts[i - start[k]];
+	for (int i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + counts[i];
+	const int64_t total = offsets[n];
 	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
-	HIPCHK(pool_alloc((void**)&f->desc, sizeof(float) * 128 * cnt));
-	HIPCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt));
-	HIPCHK(pool_alloc((void**)&f->real, sizeof(double) * 2 * cnt));
-	for (int i = 0; i < n; ++i) {
-		const op_features* p = parts[i % nparts]; const int li = i / nparts; const size_t c = (size_t)f->counts[i];
-		HIPCHK(copy_between(f->desc + f->offsets[i] * 128, dst->device, p->desc + p->offsets[li] * 128, p->device, sizeof(float) * 128 * c, dst->stream));
-		HIPCHK(copy_between(f->coor + f->offsets[i] * 2, dst->device, p->coor + p->offsets[li] * 2, p->device, sizeof(double) * 2 * c, dst->stream));
-		HIPCHK(copy_between(f->real + f->offsets[i] * 2, dst->device, p->real + p->offsets[li] * 2, p->device, sizeof(double) * 2 * c, dst->stream));
-	}
-	HIPCHK(hipStreamSynchronize(dst->stream));
-	*out = f;
-	return OP_OK;
+	std::vector<int> rcs(nctx, OP_OK);
+	std::vector<std::string> errs(nctx);
+	std::vector<std::thread> th;
+	for (int k = 0; k < nctx; ++k) tables[k] = nullptr;
+	for (int k = 0; k < nctx; ++k)
+		th.emplace_back([&, k] {
+			auto fail = [&](hipError_t e, const char* what) { errs[k] = std::string(what) + ": " + hipGetErrorString(e); rcs[k] = OP_ERR_HIP; };
+			op_ctx* dst = ctxs[k];
+			hipError_t e = hipSetDevice(dst->device);
+			if (e != hipSuccess) return fail(e, "hipSetDevice");
+			std::unique_ptr<op_features, void (*)(op_features*)> f(new op_features, op_features_free);
+			f->n = n; f->counts = counts; f->offsets = offsets; f->device = dst->device;
+			if ((e = pool_alloc((void**)&f->desc, sizeof(float) * 128 * cnt)) != hipSuccess) return fail(e, "pool_alloc");
+			if ((e = pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt)) != hipSuccess) return fail(e, "pool_alloc");
+			if ((e = pool_alloc((void**)&f->real, sizeof(double) * 2 * cnt)) != hipSuccess) return fail(e, "pool_alloc");
+			for (int s = 0; s < nctx; ++s) {
+				const int src = (k + s) % nctx;                     // start with the own slice, then rotate: no hot source
+				const op_features* p = parts[src];
+				const size_t c = (size_t)(offsets[start[src + 1]] - offsets[start[src]]);
+				const int64_t o = offsets[start[src]];
+				if ((e = copy_between(f->desc + o * 128, dst->device, p->desc, p->device, sizeof(float) * 128 * c, dst->stream)) != hipSuccess) return fail(e, "peer copy");
+				if ((e = copy_between(f->coor + o * 2, dst->device, p->coor, p->device, sizeof(double) * 2 * c, dst->stream)) != hipSuccess) return fail(e, "peer copy");
+				if ((e = copy_between(f->real + o * 2, dst->device, p->real, p->device, sizeof(double) * 2 * c, dst->stream)) != hipSuccess) return fail(e, "peer copy");
+			}
+			if ((e = hipStreamSynchronize(dst->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+			tables[k] = f.release();
+		});
+	for (auto& t : th) t.join();
+	int rc = OP_OK;
+	for (int k = 0; k < nctx; ++k) if (rcs[k] != OP_OK && rc == OP_OK) { rc = rcs[k]; op_set_error("device " + std::to_string(k) + ": " + errs[k]); }
+	if (rc != OP_OK) for (int k = 0; k < nctx; ++k) { op_features_free(tables[k]); tables[k] = nullptr; }
+	return rc;
 }
 
-// multi.hip: the whole table of f on dst's device (the all-gather step of SURVEY 8(e).2 as one peer copy per array)
+// multi.hip: the whole table of f on dst's device (one peer copy per array)
 int op_features_replicate(op_ctx* dst, const op_features* src, op_features** out) {
 	HIPCHK(hipSetDevice(dst->device));
-	op_features* f = new op_features;
+	std::unique_ptr<op_features, void (*)(op_features*)> f(new op_features, op_features_free);
 	f->n = src->n; f->counts = src->counts; f->offsets = src->offsets; f->device = dst->device; f->has_desc = src->has_desc;
 	const int64_t total = src->offsets[src->n];
 	const size_t cnt = (size_t)std::max<int64_t>(total, 1);
@@ -530,16 +572,18 @@ int op_features_replicate(op_ctx* dst, const op_features* src, op_features** out
 	if (src->has_desc) HIPCHK(copy_between(f->desc, dst->device, src->desc, src->device, sizeof(float) * 128 * (size_t)total, dst->stream));
 	HIPCHK(copy_between(f->coor, dst->device, src->coor, src->device, sizeof(double) * 2 * (size_t)total, dst->stream));
 	HIPCHK(hipStreamSynchronize(dst->stream));
-	*out = f;
+	*out = f.release();
 	return OP_OK;
 }
+std::vector<op_features*>& op_features_replicas(op_features* f) { return f->replicas; }
 
 extern "C" {
 
 void op_features_free(op_features* f) {
 	if (!f) return;
 	hipSetDevice(f->device);
-	pool_free(f->desc); pool_free(f->coor); pool_free(f->real);
+	if (f->owns) { pool_free(f->desc); pool_free(f->coor); pool_free(f->real); }
+	for (op_features* r : f->replicas) op_features_free(r);
 	delete f;
 }
 

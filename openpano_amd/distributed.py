@@ -1,9 +1,12 @@
 """Multi-GPU exchange step and sharded job of the hot path.
 
-One process per GPU.  SIFT shards by image with no communication (stitcherbase.cc:14 is the axis).
-All-pairs matching needs every image's features on every rank: ONE bucketed all-gather (RCCL over
-xGMI on GPUs, gloo in the CPU tests) of a per-rank byte bucket ``[descriptors K x 128 fp32 |
-coordinates K x 2 fp64]`` after a tiny all-gather of the per-image counts; the unordered pair list
+One process per GPU.  SIFT shards by image with no communication (stitcherbase.cc:14 is the axis): rank r
+owns a contiguous block of the image list, so its features are one contiguous slice of the image-indexed table.
+All-pairs matching needs every image's features on every rank: after a tiny all-gather of the per-image
+counts every rank allocates the table in GLOBAL image order and the shards travel as an all-gather-v -- one
+grouped send/recv series (RCCL over xGMI on GPUs: every rank pushes its slice to the other ranks over its
+own point-to-point links; gloo in the CPU tests) straight INTO the table's slices: no bucket padding, no
+concatenation, no reorder, and the library adopts the table without a copy.  The unordered pair list
 of ``Stitcher::pairwise_match`` (stitch/stitcher.cc:100) is dealt to the ranks balanced by
 ``K_i * K_j``; RANSAC follows the pair partition; the per-pair results (KBs) are all-gathered so
 that rank 0 -- which runs the host-only camera estimation and the blend -- holds the whole job.
@@ -94,8 +97,58 @@ def partition_pairs(pairs, rank: int, world: int, counts=None):
 
 
 def shard_images(n: int, rank: int, world: int):
-    """Global image ids owned by ``rank``: round-robin, so every rank gets n/world +- 1 images."""
-    return list(range(rank, n, world))
+    """Global image ids owned by ``rank``: a contiguous block of n/world (+1 on the first n % world ranks) images --
+    images of one job have one size, so blocks are as balanced as any deal, and a rank's features are ONE slice of
+    the image-indexed table (one message per peer in the exchange)."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def allgatherv_features(local_desc: torch.Tensor, local_coor: torch.Tensor, local_counts, n: int, group=None):
+    """The exchange step.  local_desc (K, 128) float32 / local_coor (K, 2) float64: this rank's images (the block
+    ``shard_images(n, rank, world)``) back to back on its device.  Returns (desc, coor, counts) of ALL n images in
+    global image order, identical on every rank: a header collective (per-image counts), then the slices are
+    sent / received in place with one grouped batch of point-to-point operations -- ncclGroupStart/End under the
+    nccl backend, i.e. every pair of GPUs exchanges its two slices over its own xGMI link concurrently."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_desc.device
+    blocks = [shard_images(n, r, world) for r in range(world)]
+    assert len(local_counts) == len(blocks[rank])
+    nmax = max(max(len(b) for b in blocks), 1)
+    hdr = torch.zeros(nmax, dtype=torch.int64, device=dev)
+    if len(local_counts):
+        hdr[: len(local_counts)] = torch.as_tensor(list(local_counts), dtype=torch.int64)
+    all_hdr = torch.empty(world * nmax, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_hdr, hdr, group=group)
+    all_hdr = all_hdr.view(world, nmax).cpu()
+    counts = [int(all_hdr[r, k]) for r in range(world) for k in range(len(blocks[r]))]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    lo = [int(offs[b[0]]) if b else 0 for b in blocks]
+    hi = [int(offs[b[-1] + 1]) if b else 0 for b in blocks]
+    total = int(offs[-1])
+    assert hi[rank] - lo[rank] == int(local_desc.shape[0])
+    gdesc = torch.empty((total, 128), dtype=torch.float32, device=dev)
+    gcoor = torch.empty((total, 2), dtype=torch.float64, device=dev)
+    if hi[rank] > lo[rank]:
+        gdesc[lo[rank]: hi[rank]].copy_(local_desc)
+        gcoor[lo[rank]: hi[rank]].copy_(local_coor)
+    ops = []
+    mine_d, mine_c = gdesc[lo[rank]: hi[rank]], gcoor[lo[rank]: hi[rank]]
+    for step in range(1, world):                          # peer order rotated by rank: no hot receiver
+        peer = (rank + step) % world
+        src = (rank - step) % world
+        if hi[rank] > lo[rank]:
+            ops.append(dist.P2POp(dist.isend, mine_d, peer, group))
+            ops.append(dist.P2POp(dist.isend, mine_c, peer, group))
+        if hi[src] > lo[src]:
+            ops.append(dist.P2POp(dist.irecv, gdesc[lo[src]: hi[src]], src, group))
+            ops.append(dist.P2POp(dist.irecv, gcoor[lo[src]: hi[src]], src, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return gdesc, gcoor, counts
 
 
 def _allgather_blob(blob: np.ndarray, device, group=None):
@@ -154,9 +207,12 @@ class HipEngine:
 
     def sift(self, images):
         """-> (desc (K,128) f32 tensor, coor (K,2) f64 tensor, counts); zero-copy views of the
-        library-owned buffers, valid until the next sift() of this engine."""
+        library-owned buffers, valid until the next sift() of this engine.  An empty shard (more ranks than
+        images) is no library call."""
         if self._feats is not None:
-            self._feats.free()
+            self._feats.free(); self._feats = None
+        if not callable(images) and len(images) == 0:
+            return torch.zeros((0, 128), device=self.device), torch.zeros((0, 2), dtype=torch.float64, device=self.device), []
         f = self._feats = self.hip.sift_batch(self.ctx, self.cfg, images) if not callable(images) else images()
         counts = [f.count(i) for i in range(f.num_images)]
         if int(f.total) == 0:
@@ -166,8 +222,8 @@ class HipEngine:
         return desc, coor, counts
 
     def table(self, desc, coor, counts):
-        """image-indexed feature table in this rank's HBM (op_features_from_device)"""
-        return self.hip.Features.from_device(self.ctx, desc.data_ptr(), counts, coor.data_ptr() if coor is not None else None)
+        """image-indexed feature table in this rank's HBM: the library adopts the exchanged buffers (no copy)"""
+        return self.hip.Features.adopt_device(self.ctx, desc.data_ptr(), counts, coor.data_ptr(), keep=(desc, coor))
 
     def match(self, table, pairs):
         """-> (handle, [(M,2) int32])"""
@@ -232,18 +288,10 @@ class ShardedJob:
         return sum(self.counts)
 
     def exchange(self):
-        if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the collective really runs
-            gdesc, gcoor, rcounts, nimg = allgather_features(self.desc, self.coor, self.counts, self.group)
-            owner_order = [g for r in range(self.world) for g in shard_images(self.n, r, self.world)]
-            assert [len(shard_images(self.n, r, self.world)) for r in range(self.world)] == nimg
-            # the bucket arrives rank-major; the table is rebuilt in GLOBAL image order so that pair
-            # (i, j), its match list and its RANSAC draw sequence are those of the single-rank job
-            offs = np.concatenate([[0], np.cumsum(rcounts)])
-            pos = {g: k for k, g in enumerate(owner_order)}
-            sl = [slice(int(offs[pos[g]]), int(offs[pos[g] + 1])) for g in range(self.n)]
-            gcounts = [rcounts[pos[g]] for g in range(self.n)]
-            gdesc = torch.cat([gdesc[x] for x in sl], 0).contiguous()
-            gcoor = torch.cat([gcoor[x] for x in sl], 0).contiguous()
+        if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the header collective really runs
+            # slices arrive in place, in GLOBAL image order: pair (i, j), its match list and its RANSAC draw
+            # sequence are those of the single-rank job whatever the world size
+            gdesc, gcoor, gcounts = allgatherv_features(self.desc, self.coor, self.counts, self.n, self.group)
         else:
             gdesc, gcoor, gcounts = self.desc, self.coor, self.counts
         if self.tab is not None:

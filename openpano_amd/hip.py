@@ -125,6 +125,7 @@ def lib():
     L.op_features_copy_real.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.op_features_from_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_features_adopt_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_free.argtypes = [C.c_void_p]
     L.op_sift_staged.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.POINTER(C.c_void_p)]
     L.op_sift_dump_free.argtypes = [C.c_void_p]
@@ -155,6 +156,8 @@ def lib():
     L.op_group_ctx.argtypes = [C.c_void_p, C.c_int]
     L.op_sift_batch_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
     L.op_match_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.op_ransac_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.op_matches_from_host.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_ransac_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -268,6 +271,18 @@ class Group:
         check(lib().op_match_pairs_multi(self.handle, C.byref(ccfg), feats.handle, pr.ctypes.data_as(C.c_void_p), len(pr), C.byref(h)))
         return Matches(h, len(pr))
 
+    def ransac_pairs(self, cfg, feats, matches, pairs, shapes_wh, seeds=None, base_seed=0):
+        """op_ransac_pairs_multi -> the same list of dicts as hip.ransac_pairs"""
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+        sd = np.ascontiguousarray(np.asarray(seeds, np.uint32)) if seeds is not None else None
+        ccfg = OpConfig.from_config(cfg)
+        h = C.c_void_p()
+        check(lib().op_ransac_pairs_multi(self.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
+                                          sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
+                                          int(base_seed), C.byref(h)))
+        return _unpack_ransac(h, len(pr))
+
     def close(self):
         if self.handle:
             self.ctx0.close()
@@ -366,6 +381,18 @@ class Features:
         h = C.c_void_p()
         check(lib().op_features_from_device(ctx.handle, C.c_void_p(int(desc_ptr)), C.c_void_p(int(coor_ptr)) if coor_ptr else None, cc, n, C.byref(h)))
         return cls(ctx, h)
+
+    @classmethod
+    def adopt_device(cls, ctx, desc_ptr, counts, coor_ptr, keep=None):
+        """flat device buffers (images back to back) -> Features WITHOUT a copy; `keep` (e.g. the torch tensors that own
+        the memory) is held until free()"""
+        n = len(counts)
+        cc = (C.c_int * n)(*[int(c) for c in counts])
+        h = C.c_void_p()
+        check(lib().op_features_adopt_device(ctx.handle, C.c_void_p(int(desc_ptr)), C.c_void_p(int(coor_ptr)), cc, n, C.byref(h)))
+        f = cls(ctx, h)
+        f._keep = keep
+        return f
 
     def desc_device_array(self):
         """object exposing ``__cuda_array_interface__`` over the device descriptor buffer
@@ -559,9 +586,14 @@ def ransac_pairs(ctx: Context, cfg, feats: Features, matches: Matches, pairs, sh
     check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
                             sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
                             int(base_seed), C.byref(h)))
+    return _unpack_ransac(h, len(pr))
+
+
+def _unpack_ransac(h, npairs):
+    L = lib()
     out = []
     try:
-        for p in range(len(pr)):
+        for p in range(npairs):
             homo = np.zeros(9, np.float64)
             check(L.op_ransac_homo(h, p, homo.ctypes.data_as(C.c_void_p)))
             n = L.op_ransac_inlier_count(h, p)

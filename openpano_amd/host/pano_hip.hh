@@ -384,9 +384,14 @@ inline void hip_match_and_estimate(const HipFeatureSet& fs, const std::vector<Sh
 	for (auto& t : tasks) { pr.push_back(t.first); pr.push_back(t.second); }
 	for (auto& s : shapes) { sh.push_back(s.w); sh.push_back(s.h); }
 	op_matches* m = nullptr;
-	PANO_HIP_CHECK(op_match_pairs(ctx, &cfg, fs.handle, pr.data(), (int)tasks.size(), &m));
 	op_ransac_result* r = nullptr;
-	PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), seeds.empty() ? nullptr : seeds.data(), base_seed, &r));
+	if (op_group* g = HipContext::group()) {           // pair list dealt over the group's GPUs; RANSAC follows the deal
+		PANO_HIP_CHECK(op_match_pairs_multi(g, &cfg, fs.handle, pr.data(), (int)tasks.size(), &m));
+		PANO_HIP_CHECK(op_ransac_pairs_multi(g, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), seeds.empty() ? nullptr : seeds.data(), base_seed, &r));
+	} else {
+		PANO_HIP_CHECK(op_match_pairs(ctx, &cfg, fs.handle, pr.data(), (int)tasks.size(), &m));
+		PANO_HIP_CHECK(op_ransac_pairs(ctx, &cfg, fs.handle, m, pr.data(), (int)tasks.size(), sh.data(), seeds.empty() ? nullptr : seeds.data(), base_seed, &r));
+	}
 	std::vector<int64_t> off(tasks.size() + 1);
 	std::vector<int> idx((size_t)op_matches_total(m) * 2 + 2);
 	PANO_HIP_CHECK(op_matches_copy_all(m, idx.data(), off.data()));

@@ -104,10 +104,10 @@ def _job_views():
     return [synth.cut_view(world, 20 + 6 * k, 20 + 110 * k, 200, 280, 70 + k) for k in range(5)]
 
 
-def _run_job(group_world):
+def _run_job(group_world, nviews=5):
     from openpano_amd.config import PanoConfig
     from openpano_amd.distributed import ShardedJob
-    views = _job_views()
+    views = _job_views()[:nviews]
     job = ShardedJob(OracleEngine(PanoConfig()), len(views), torch.device("cpu"))
     assert job.world == group_world
     k_local = job.sift([views[g] for g in job.local_ids])
@@ -119,10 +119,10 @@ def _run_job(group_world):
     return k_local, k_total, job.gcounts, job.my_pairs, {k: (m.tolist(), ex.tolist()) for k, (m, ex) in res.items()}
 
 
-def _job_worker(rank, world, port, q):
+def _job_worker(rank, world, port, q, nviews=5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    q.put((rank,) + _run_job(world))
+    q.put((rank,) + _run_job(world, nviews))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -160,3 +160,27 @@ def test_sharded_job_equals_single_rank(world):
         assert np.array_equal(np.array(oa[p][1]), np.array(out1[p][1]), equal_nan=True), p
         nok += out1[p][1][0] > 0
     assert nok >= 3
+
+
+def test_more_ranks_than_images():
+    """world 3, two images: the third rank owns no image (an empty shard goes through every collective without a
+    library call) and no pair; the job still equals the single-rank job on every rank."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    single = _run_job(1, 2)
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res][2] == 0 and sum(r[1] for r in res) == single[1]
+    assert sum(len(r[4]) for r in res) == 1
+    assert all(r[5] == res[0][5] for r in res) and sorted(res[0][5]) == sorted(single[4])
+    for p in single[4]:
+        assert res[0][5][p][0] == single[4][p][0]

@@ -42,6 +42,20 @@ def test_group_sift_and_match_equal_single_device(cfg, devices):
     assert sum(len(m) for m in want) > 100
     for k in range(len(pairs)):
         assert np.array_equal(want[k], got[k]) and np.array_equal(want[k], got2[k]), pairs[k]
+    # RANSAC over the group follows the pair deal (lists resident per device) and equals the single-device call,
+    # with explicit seeds and with seeds derived from the base seed and the JOB's pair index
+    shapes = [(im.shape[1], im.shape[0]) for im in imgs]
+    mh1 = hip.match_pairs_handle(ctx, cfg, single, pairs)
+    mhg = grp.match_pairs_handle(cfg, multi, pairs)
+    for kw in (dict(seeds=[70 + k for k in range(len(pairs))]), dict(base_seed=5)):
+        r1 = hip.ransac_pairs(ctx, cfg, single, mh1, pairs, shapes, **kw)
+        rg = grp.ransac_pairs(cfg, multi, mhg, pairs, shapes, **kw)
+        rh = grp.ransac_pairs(cfg, multi, mh1, pairs, shapes, **kw)      # matched on one device: runs on context 0
+        for k in range(len(pairs)):
+            for r in (rg, rh):
+                assert r[k]["ok"] == r1[k]["ok"] and r[k]["best_hyp"] == r1[k]["best_hyp"] and r[k]["confidence"] == r1[k]["confidence"], pairs[k]
+                assert np.array_equal(r[k]["inliers"], r1[k]["inliers"]) and np.array_equal(r[k]["homo"], r1[k]["homo"]), pairs[k]
+    mh1.free(); mhg.free()
     # fewer items than devices; one image; no pairs
     one = grp.sift_batch(cfg, imgs[:1])
     assert np.array_equal(one.get(0)[0], single.get(0)[0])
