@@ -83,7 +83,9 @@ int op_ctx_profile_get(op_ctx* ctx, int i, const char** label, double* total_ms,
 typedef struct op_image {
 	const void* data;    /* H x W x 3, row-major interleaved RGB; element type per dtype */
 	int h, w;
-	int on_device;       /* 0: host pointer (copied H2D inside the call), 1: device pointer */
+	int on_device;       /* 0: host pointer (copied H2D inside the call), 1: device pointer.  Host images of a batch that lie at
+	                      * one constant stride >= their size (a contiguous array of frames, a decoder pool) go up in ONE copy;
+	                      * pinned memory copies at the link rate */
 	int dtype;           /* OP_F32 (0): fp32 in [0,1] = Mat32f ; OP_U8 (1): decoder bytes, converted on the
 	                      * device exactly like read_img does, (float)byte / 255.0 (lib/imgio.cc:54-56,75-77):
 	                      * a quarter of the PCIe / HBM traffic of the fp32 image */

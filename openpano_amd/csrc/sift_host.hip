@@ -255,12 +255,17 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	if (host_bytes) HIPCHK(W.staging.ensure(host_bytes));
 	{
 		const void** hs = (const void**)W.pinned;
-		// host images that lie back to back at the staging stride (a decoder's output pool, one pinned block
-		// sliced into frames) travel in ONE copy: 38 separate 3 MB copies reach about half the link rate
+		// host images that lie at ONE constant stride >= their size (a decoder's output pool, one block sliced into
+		// frames; a contiguous array of images: stride == size) travel in ONE strided copy: 38 separate 3 MB copies
+		// reach about half the link rate.  Any other arrangement is copied image by image.
 		bool packed = host_bytes == img_stride * (size_t)n && n > 1;
-		for (int i = 1; i < n && packed; ++i) packed = (const char*)imgs[i]->data == (const char*)imgs[0]->data + (size_t)i * img_stride;
+		ptrdiff_t hstride = 0;
+		if (packed) hstride = (const char*)imgs[1]->data - (const char*)imgs[0]->data;
+		packed = packed && hstride >= (ptrdiff_t)img_bytes;
+		for (int i = 2; i < n && packed; ++i) packed = (const char*)imgs[i]->data - (const char*)imgs[i - 1]->data == hstride;
 		if (packed) {
-			HIPCHK(hipMemcpyAsync(W.staging.p, imgs[0]->data, img_stride * (size_t)(n - 1) + img_bytes, hipMemcpyHostToDevice, st));
+			if ((size_t)hstride == img_stride) HIPCHK(hipMemcpyAsync(W.staging.p, imgs[0]->data, img_stride * (size_t)(n - 1) + img_bytes, hipMemcpyHostToDevice, st));
+			else HIPCHK(hipMemcpy2DAsync(W.staging.p, img_stride, imgs[0]->data, (size_t)hstride, img_bytes, (size_t)n, hipMemcpyHostToDevice, st));
 			for (int i = 0; i < n; ++i) hs[i] = (char*)W.staging.p + (size_t)i * img_stride;
 		} else {
 			size_t so = 0;

@@ -212,6 +212,7 @@ class IncrementalBundleAdjuster {
 			match_cnt_prefix_sum.emplace_back(nr_pointwise_match);
 			nr_pointwise_match += (int)m.match.size();
 			idx_added.insert(i); idx_added.insert(j);
+			++topo_gen;                              // the pair / index tables below are stale from here on
 		}
 		void set_identity_idx(int idx) { identity_idx = idx; }
 
@@ -271,7 +272,7 @@ class IncrementalBundleAdjuster {
 		int identity_idx = -1;
 		std::set<int> idx_added;
 		std::vector<int> index_map, match_cnt_prefix_sum;
-		void update_index_map() { int cnt = 0; for (auto& i : idx_added) index_map[i] = cnt++; }
+		void update_index_map() { int cnt = 0; for (auto& i : idx_added) index_map[i] = cnt++; ++topo_gen; }
 
 		struct ParamState {
 			std::vector<Camera> cameras;
@@ -384,10 +385,12 @@ class IncrementalBundleAdjuster {
 		std::vector<double> deriv;          // 24 doubles per pointwise match: dx[0..11], dy[0..11]
 		std::vector<std::vector<int>> cam_pairs;                       // per camera: match-pair indices touching it, ascending
 		std::vector<std::pair<std::pair<int, int>, std::vector<int>>> block_pairs;    // per connected camera pair (i < j): match-pair indices, ascending
-		size_t topo_pairs = (size_t)-1; int topo_imgs = -1;
+		// the tables are rebuilt whenever a mutator (add_match, update_index_map) ran since they were built:
+		// a generation counter, not the container sizes (a replaced pair keeps the sizes and changes the tables)
+		unsigned long topo_gen = 0, topo_built = (unsigned long)-1; int topo_imgs = -1;
 
 		void update_topology(int nr_img) {
-			if (topo_pairs == match_pairs.size() && topo_imgs == nr_img) return;
+			if (topo_built == topo_gen && topo_imgs == nr_img) return;
 			cam_pairs.assign(nr_img, {});
 			std::vector<std::vector<int>> blk((size_t)nr_img * nr_img);
 			for (size_t q = 0; q < match_pairs.size(); ++q) {
@@ -399,7 +402,7 @@ class IncrementalBundleAdjuster {
 			block_pairs.clear();
 			for (int i = 0; i < nr_img; ++i) for (int j = i + 1; j < nr_img; ++j)
 				if (!blk[(size_t)i * nr_img + j].empty()) block_pairs.push_back({{i, j}, std::move(blk[(size_t)i * nr_img + j])});
-			topo_pairs = match_pairs.size(); topo_imgs = nr_img;
+			topo_built = topo_gen; topo_imgs = nr_img;
 		}
 
 		void calcJacobianSymbolic(const ParamState& state, const std::vector<double>& residual) {

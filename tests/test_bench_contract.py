@@ -55,3 +55,34 @@ def test_cpu_baseline_leg_runs_and_reports_what_it_did(cfg):
     assert r["kind"] in ("reference", "port") and r["value"] > 0 and r["single_thread_value"] > 0
     assert 1 <= r["cores"] <= (os.cpu_count() or 1) and r["cores"] <= 2 * (os.cpu_count() or 1)
     assert r["cpu_model"] and "best of 3" in r["sample"] and r["flags"]
+
+
+def test_committed_bench_lines_obey_the_contract():
+    """The newest committed bench line of every round (profiles/rNN_bench_vM.json): contract keys, a roofline object
+    that is consistent with itself (achieved = algorithmic bytes / launch time, frac = achieved / peak), parity
+    checked in the run, value = descriptors * steps / time and above the north_star's 30x of the CPU baseline."""
+    import glob
+    import json
+    import re
+    newest = {}
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_v*.json")):
+        m = re.match(r"r(\d+)_bench_v(\d+)\.json$", os.path.basename(f))
+        if m and (int(m.group(1)) not in newest or int(m.group(2)) > newest[int(m.group(1))][0]):
+            newest[int(m.group(1))] = (int(m.group(2)), f)
+    assert newest
+    for rnd, (_, f) in sorted(newest.items()):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in d, (f, k)
+        assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert r["avg_launch_ms"] <= d["ms_per_step"]
+        if rnd >= 2:
+            assert d["parity_checked"] is True, f
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["sample"]
+        assert d["value"] > 30 * c["value"], (f, d["value"] / c["value"])
+        k = d["config"]["keypoints_per_image"] * d["config"]["images_per_gpu"]
+        assert abs(d["value"] - k / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"], f

@@ -263,3 +263,23 @@ def test_raw_capacity_overflow_reruns_instead_of_failing(oracle, cfg):
         f.free()
     finally:
         c.close()
+
+
+def test_host_images_at_a_constant_stride_travel_in_one_copy(ctx, oracle, cfg):
+    """Host images that are slices of one array (np.stack: stride == image size; a padded pool: larger stride) take the
+    single strided H2D copy of op_sift_batch; separately allocated images take one copy each.  Same features."""
+    from openpano_amd import hip
+    views = synth.image_set(3, 240, 320, seed=9, overlap=0.5)
+    want = [oracle.detect_feature(v) for v in views]
+    stack = np.ascontiguousarray(np.stack(views))                        # stride == image bytes
+    pool = np.zeros((3, 240 * 320 * 3 + 77), np.float32)                 # a larger constant stride, not a multiple of 256 bytes
+    pooled = []
+    for k, v in enumerate(views):
+        pool[k, : v.size] = v.reshape(-1)
+        pooled.append(pool[k, : v.size].reshape(v.shape))
+    for imgs in ([stack[0], stack[1], stack[2]], pooled, [v.copy() for v in views]):
+        f = hip.sift_batch(ctx, cfg, imgs)
+        for i in range(3):
+            d, c = f.get(i)
+            assert np.array_equal(d, want[i][0]) and np.array_equal(c, want[i][1]), i
+        f.free()
