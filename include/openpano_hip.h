@@ -104,6 +104,14 @@ enum { OP_F32 = 0, OP_U8 = 1 };
  * ===================================================================================== */
 typedef struct op_features op_features;
 int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n, op_features** out);
+/* The same for HOST images with the transfers overlapped (StitcherBase::calc_feature end to end, stitch/stitcherbase.cc:9-27:
+ * Mat32f / decoder bytes in host memory in, descriptors and keypoint coordinates in host memory out).  The batch runs as
+ * a pipeline over chunks: uploads on one copy stream, kernels on the context's stream, results on a second copy stream
+ * into desc_out (rows x 128 fp32) / coor_out (rows x 2 fp64), images back to back, capacity_rows rows of room (either
+ * pointer may be NULL; pinned memory copies at the link rate).  *out receives the resident features as op_sift_batch
+ * does.  OP_ERR_CAPACITY (with *out still set) when the host buffers are too small. */
+int op_sift_batch_host(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n,
+		float* desc_out, double* coor_out, int64_t capacity_rows, op_features** out);
 int op_features_num_images(const op_features* f);
 /* number of descriptors of image i (K_i) and the exclusive prefix offset of its first row */
 int op_features_count(const op_features* f, int i);

@@ -178,7 +178,7 @@ int op_ctx_profile_get(op_ctx* c, int i, const char** label, double* total_ms, l
 }
 
 const char* op_last_error(void) { return g_last_error.c_str(); }
-int op_abi_version(void) { return 3; }      // 3: op_blend_image.mat_h / mat_w
+int op_abi_version(void) { return 4; }      // 3: op_blend_image.mat_h / mat_w; 4: resident match lists, op_sift_batch_host, op_ransac_pairs_multi
 
 void op_config_default(op_config* c) {
 	// src/config.cfg (every literal goes through a float, lib/config.cc:19-26)
@@ -227,6 +227,8 @@ void op_ctx_destroy(op_ctx* c) {
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
 	if (c->pinned) hipHostFree(c->pinned);
+	if (c->h2d_stream) hipStreamDestroy(c->h2d_stream);
+	if (c->d2h_stream) hipStreamDestroy(c->d2h_stream);
 	if (c->owns_stream) hipStreamDestroy(c->stream);
 	delete c;
 }

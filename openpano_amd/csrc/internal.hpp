@@ -47,6 +47,13 @@ struct op_ctx {
 		void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 	};
 	DevScratch match_arena, ransac_arena;
+	// copy streams of the host-image pipeline (op_sift_batch_host): uploads run ahead of the kernels, results leave behind them
+	hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+	hipError_t copy_streams() {
+		if (!h2d_stream) { hipError_t e = hipStreamCreateWithFlags(&h2d_stream, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+		if (!d2h_stream) { hipError_t e = hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+		return hipSuccess;
+	}
 	void* pinned_scratch(size_t bytes) {
 		if (bytes <= pinned_cap) return pinned;
 		if (pinned) hipHostFree(pinned);

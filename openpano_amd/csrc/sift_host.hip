@@ -420,6 +420,108 @@ int op_sift_batch(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n
 	return OP_OK;
 }
 
+// StitcherBase::calc_feature end to end for HOST images (stitch/stitcherbase.cc:9-27: Mat32f in host memory in,
+// descriptors and keypoints in host memory out) as a three-stage pipeline over chunks of the batch: the uploads of
+// all chunks are queued on a copy stream at once, the kernels of chunk k start when its upload has landed, and its
+// results leave on a second copy stream while chunk k+1 computes -- PCIe in, kernels and PCIe out overlap instead of
+// running back to back.  Images of one size and element type (the usual job); anything else takes op_sift_batch.
+int op_sift_batch_host(op_ctx* ctx, const op_config* cfg, const op_image* imgs, int n,
+		float* desc_out, double* coor_out, int64_t capacity_rows, op_features** out) {
+	if (!ctx || !cfg || !imgs || n <= 0 || !out || capacity_rows < 0) OP_FAIL(OP_ERR_INVALID, "op_sift_batch_host: bad argument");
+	bool uniform = true;
+	for (int i = 0; i < n; ++i) {
+		if (!imgs[i].data || imgs[i].h < 2 || imgs[i].w < 2 || (imgs[i].dtype != OP_F32 && imgs[i].dtype != OP_U8)) OP_FAIL(OP_ERR_INVALID, "op_sift_batch_host: bad image " + std::to_string(i));
+		uniform = uniform && !imgs[i].on_device && imgs[i].h == imgs[0].h && imgs[i].w == imgs[0].w && imgs[i].dtype == imgs[0].dtype;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const int nchunks = uniform ? std::max(1, std::min(6, n / 8)) : 1;
+	if (nchunks == 1) {                      // nothing to overlap: the plain call, then one copy out
+		int rc = op_sift_batch(ctx, cfg, imgs, n, out);
+		if (rc != OP_OK) return rc;
+		const int64_t total = (*out)->offsets[n];
+		if ((desc_out || coor_out) && total > capacity_rows) OP_FAIL(OP_ERR_CAPACITY, "op_sift_batch_host: " + std::to_string(total) + " descriptors, room for " + std::to_string(capacity_rows));
+		if (desc_out && total) HIPCHK(hipMemcpyAsync(desc_out, (*out)->desc, sizeof(float) * 128 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+		if (coor_out && total) HIPCHK(hipMemcpyAsync(coor_out, (*out)->coor, sizeof(double) * 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(hipStreamSynchronize(ctx->stream));
+		return OP_OK;
+	}
+	HIPCHK(ctx->copy_streams());
+	Workspace* W = ctx_workspace(ctx);
+	const size_t img_bytes = (imgs[0].dtype == OP_U8 ? 1 : sizeof(float)) * (size_t)imgs[0].h * imgs[0].w * 3;
+	const size_t img_stride = (img_bytes + 255) & ~(size_t)255;
+	HIPCHK(W->staging.ensure(img_stride * (size_t)n));
+	std::vector<int> cb(nchunks + 1, 0);
+	for (int k = 0; k < nchunks; ++k) cb[k + 1] = cb[k] + n / nchunks + (k < n % nchunks ? 1 : 0);
+	// constant host stride -> one (strided) copy per chunk
+	ptrdiff_t hstride = n > 1 ? (const char*)imgs[1].data - (const char*)imgs[0].data : (ptrdiff_t)img_bytes;
+	bool strided = hstride >= (ptrdiff_t)img_bytes;
+	for (int i = 2; i < n && strided; ++i) strided = (const char*)imgs[i].data - (const char*)imgs[i - 1].data == hstride;
+	std::vector<hipEvent_t> ev(nchunks, nullptr);
+	std::vector<GroupResult> results(nchunks);
+	std::unique_ptr<op_features, void (*)(op_features*)> f(new op_features, op_features_free);
+	f->n = n; f->counts.assign(n, 0); f->offsets.assign(n + 1, 0); f->device = ctx->device;
+	int rc = OP_OK;
+	auto cleanup = [&] {
+		hipStreamSynchronize(ctx->h2d_stream); hipStreamSynchronize(ctx->d2h_stream); hipStreamSynchronize(ctx->stream);
+		for (auto& r : results) { pool_free(r.desc); pool_free(r.coor); pool_free(r.real); r.desc = nullptr; r.coor = nullptr; r.real = nullptr; }
+		for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+	};
+#define PCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return OP_ERR_HIP; } } while (0)
+	for (int k = 0; k < nchunks; ++k) {
+		char* dst = (char*)W->staging.p + (size_t)cb[k] * img_stride;
+		const int m = cb[k + 1] - cb[k];
+		if (strided) PCHK(hipMemcpy2DAsync(dst, img_stride, imgs[cb[k]].data, (size_t)hstride, img_bytes, (size_t)m, hipMemcpyHostToDevice, ctx->h2d_stream));
+		else for (int i = 0; i < m; ++i) PCHK(hipMemcpyAsync(dst + (size_t)i * img_stride, imgs[cb[k] + i].data, img_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+		PCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+		PCHK(hipEventRecord(ev[k], ctx->h2d_stream));
+	}
+	int64_t rows = 0;
+	bool overflow = false;
+	for (int k = 0; k < nchunks; ++k) {
+		const int m = cb[k + 1] - cb[k];
+		std::vector<op_image> dev(m);
+		std::vector<const op_image*> gi(m);
+		for (int i = 0; i < m; ++i) {
+			dev[i] = imgs[cb[k] + i]; dev[i].data = (char*)W->staging.p + (size_t)(cb[k] + i) * img_stride; dev[i].on_device = 1;
+			gi[i] = &dev[i];
+		}
+		PCHK(hipStreamWaitEvent(ctx->stream, ev[k], 0));
+		SiftPlan plan;
+		rc = run_group(ctx, *cfg, gi, *W, plan, results[k], nullptr);
+		if (rc != OP_OK) { cleanup(); return rc; }
+		for (int i = 0; i < m; ++i) f->counts[cb[k] + i] = results[k].counts[i];
+		const int64_t t = results[k].total;
+		if ((desc_out || coor_out) && rows + t > capacity_rows) overflow = true;
+		if (!overflow && t) {
+			if (desc_out) PCHK(hipMemcpyAsync(desc_out + rows * 128, results[k].desc, sizeof(float) * 128 * (size_t)t, hipMemcpyDeviceToHost, ctx->d2h_stream));
+			if (coor_out) PCHK(hipMemcpyAsync(coor_out + rows * 2, results[k].coor, sizeof(double) * 2 * (size_t)t, hipMemcpyDeviceToHost, ctx->d2h_stream));
+		}
+		rows += t;
+	}
+	for (int i = 0; i < n; ++i) f->offsets[i + 1] = f->offsets[i] + f->counts[i];
+	{	// the resident table of the whole batch (the matcher's input): chunk results back to back
+		const size_t cnt = (size_t)std::max<int64_t>(rows, 1);
+		PCHK(pool_alloc((void**)&f->desc, sizeof(float) * 128 * cnt));
+		PCHK(pool_alloc((void**)&f->coor, sizeof(double) * 2 * cnt));
+		PCHK(pool_alloc((void**)&f->real, sizeof(double) * 2 * cnt));
+		int64_t o = 0;
+		for (int k = 0; k < nchunks; ++k) {
+			const size_t t = (size_t)results[k].total;
+			if (t) {
+				PCHK(hipMemcpyAsync(f->desc + o * 128, results[k].desc, sizeof(float) * 128 * t, hipMemcpyDeviceToDevice, ctx->stream));
+				PCHK(hipMemcpyAsync(f->coor + o * 2, results[k].coor, sizeof(double) * 2 * t, hipMemcpyDeviceToDevice, ctx->stream));
+				PCHK(hipMemcpyAsync(f->real + o * 2, results[k].real, sizeof(double) * 2 * t, hipMemcpyDeviceToDevice, ctx->stream));
+			}
+			o += (int64_t)t;
+		}
+	}
+#undef PCHK
+	cleanup();
+	*out = f.release();
+	if (overflow) OP_FAIL(OP_ERR_CAPACITY, "op_sift_batch_host: " + std::to_string(rows) + " descriptors, room for " + std::to_string(capacity_rows) + " (the resident features are returned)");
+	return OP_OK;
+}
+
 int op_debug_set_raw_capacity(op_ctx* ctx, int cap) {
 	if (!ctx || cap < 64) OP_FAIL(OP_ERR_INVALID, "op_debug_set_raw_capacity: bad argument");
 	ctx_workspace(ctx)->raw_cap = cap;

@@ -111,6 +111,7 @@ def lib():
     L.op_ctx_profile_count.argtypes = [C.c_void_p]
     L.op_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.op_sift_batch.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
+    L.op_sift_batch_host.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.op_features_num_images.argtypes = [C.c_void_p]
     L.op_features_count.argtypes = [C.c_void_p, C.c_int]
     L.op_features_offset.restype = C.c_int64
@@ -451,6 +452,28 @@ class SiftCall:
     def __call__(self) -> Features:
         h = C.c_void_p()
         check(self._fn(self.ctx.handle, C.byref(self.ccfg), self.arr, self.n, C.byref(h)))
+        return Features(self.ctx, h)
+
+
+class SiftHostCall:
+    """op_sift_batch_host with its arguments marshalled once: host images in, descriptors / coordinates into the given
+    host buffers (raw pointers, e.g. pinned torch tensors' data_ptr()), transfers overlapped with the kernels."""
+
+    def __init__(self, ctx: Context, cfg, images, desc_ptr, coor_ptr, capacity_rows):
+        self.ctx = ctx
+        self.arr, self.keep = _mk_images(images)
+        self.n = len(images)
+        self.ccfg = OpConfig.from_config(cfg)
+        self.desc_ptr = C.c_void_p(int(desc_ptr)) if desc_ptr else None
+        self.coor_ptr = C.c_void_p(int(coor_ptr)) if coor_ptr else None
+        self.cap = int(capacity_rows)
+
+    def __call__(self) -> Features:
+        h = C.c_void_p()
+        rc = lib().op_sift_batch_host(self.ctx.handle, C.byref(self.ccfg), self.arr, self.n, self.desc_ptr, self.coor_ptr, self.cap, C.byref(h))
+        if rc != 0 and h:
+            lib().op_features_free(h)           # OP_ERR_CAPACITY still hands over the resident features
+        check(rc)
         return Features(self.ctx, h)
 
 

@@ -193,11 +193,29 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 			std::vector<op_image> ims;
 			for (auto* m : imgs) ims.push_back(op_image{m->ptr(), m->rows(), m->cols(), 0, OP_F32});
 			HipFeatureSet fs;
-			if (op_group* g = HipContext::group()) {        // images dealt over the group's GPUs, features gathered on its first
+			std::vector<float> desc; std::vector<double> coor;
+			if (op_group* g = HipContext::group()) {        // images dealt over the group's GPUs, features all-gathered
 				PANO_HIP_CHECK(op_sift_batch_multi(g, &cfg, ims.data(), (int)ims.size(), &fs.handle));
 				ctx = op_group_ctx(g, 0);
-			} else
-				PANO_HIP_CHECK(op_sift_batch(ctx, &cfg, ims.data(), (int)ims.size(), &fs.handle));
+				const size_t total = (size_t)op_features_total(fs.handle);
+				desc.resize(total * 128 + 1); coor.resize(total * 2 + 1);
+				for (size_t k = 0; k < imgs.size(); ++k)
+					if (op_features_count(fs.handle, (int)k))
+						PANO_HIP_CHECK(op_features_copy(ctx, fs.handle, (int)k, desc.data() + (size_t)op_features_offset(fs.handle, (int)k) * 128,
+								coor.data() + (size_t)op_features_offset(fs.handle, (int)k) * 2));
+			} else {
+				// uploads, kernels and the copy back to the host pipelined over chunks of the batch; the host buffers are
+				// sized from a first guess and the call repeated once if the images hold more features than that
+				size_t cap = (size_t)imgs.size() * 4096;
+				for (int attempt = 0; attempt < 2; ++attempt) {
+					desc.resize(cap * 128 + 1); coor.resize(cap * 2 + 1);
+					const int rc = op_sift_batch_host(ctx, &cfg, ims.data(), (int)ims.size(), desc.data(), coor.data(), (int64_t)cap, &fs.handle);
+					if (rc == OP_OK) break;
+					if (rc != OP_ERR_CAPACITY || attempt == 1) hip_error_exit("op_sift_batch_host");
+					cap = (size_t)op_features_total(fs.handle) + 16;
+					op_features_free(fs.handle); fs.handle = nullptr;
+				}
+			}
 			fs.feats.resize(imgs.size());
 			for (size_t k = 0; k < imgs.size(); ++k) {
 				const int n = op_features_count(fs.handle, (int)k);
@@ -205,13 +223,12 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 					fprintf(stderr, "Cannot find feature in image %d!\n", (int)k);
 					exit(1);
 				}
-				std::vector<float> desc((size_t)n * 128);
-				std::vector<double> coor((size_t)n * 2);
-				PANO_HIP_CHECK(op_features_copy(ctx, fs.handle, (int)k, desc.data(), coor.data()));
+				const float* d = desc.data() + (size_t)op_features_offset(fs.handle, (int)k) * 128;
+				const double* c = coor.data() + (size_t)op_features_offset(fs.handle, (int)k) * 2;
 				fs.feats[k].resize(n);
 				for (int i = 0; i < n; ++i) {
-					fs.feats[k][i].coor = Vec2D(coor[2 * i], coor[2 * i + 1]);
-					fs.feats[k][i].descriptor.assign(desc.begin() + (size_t)i * 128, desc.begin() + (size_t)(i + 1) * 128);
+					fs.feats[k][i].coor = Vec2D(c[2 * i], c[2 * i + 1]);
+					fs.feats[k][i].descriptor.assign(d + (size_t)i * 128, d + (size_t)(i + 1) * 128);
 				}
 			}
 			return fs;

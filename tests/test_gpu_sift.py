@@ -283,3 +283,30 @@ def test_host_images_at_a_constant_stride_travel_in_one_copy(ctx, oracle, cfg):
             d, c = f.get(i)
             assert np.array_equal(d, want[i][0]) and np.array_equal(c, want[i][1]), i
         f.free()
+
+
+def test_pipelined_host_call_equals_the_plain_call(ctx, cfg):
+    """op_sift_batch_host (uploads / kernels / copy back pipelined over chunks) returns the features op_sift_batch
+    returns, resident and in the caller's host buffers; a host buffer that is too small is OP_ERR_CAPACITY."""
+    from openpano_amd import hip
+    views = synth.image_set(17, 240, 320, seed=11, overlap=0.5)                 # 17 images -> 2 chunks of 9 + 8
+    plain = hip.sift_batch(ctx, cfg, views)
+    total = int(plain.total)
+    for imgs in (views, [(v * 255 + 0.5).astype(np.uint8) for v in views]):
+        ref = plain if imgs is views else hip.sift_batch(ctx, cfg, imgs)
+        total = int(ref.total)
+        hd = np.zeros((total + 8, 128), np.float32); hc = np.zeros((total + 8, 2), np.float64)
+        f = hip.SiftHostCall(ctx, cfg, imgs, hd.ctypes.data, hc.ctypes.data, total + 8)()
+        assert f.num_images == 17 and int(f.total) == total
+        for i in range(17):
+            d, c = f.get(i); rd, rc = ref.get(i)
+            assert np.array_equal(d, rd) and np.array_equal(c, rc), i
+            o = f.offset(i)
+            assert np.array_equal(hd[o: o + len(d)], rd) and np.array_equal(hc[o: o + len(d)], rc), i
+            assert np.array_equal(f.get_real(i), ref.get_real(i))
+        f.free()
+        with pytest.raises(hip.OpenPanoHipError):
+            hip.SiftHostCall(ctx, cfg, imgs, hd.ctypes.data, hc.ctypes.data, total - 1)()
+        if ref is not plain:
+            ref.free()
+    plain.free()
