@@ -111,7 +111,8 @@ def lib():
     L.op_ctx_profile_count.argtypes = [C.c_void_p]
     L.op_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.op_sift_batch.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
-    L.op_sift_batch_host.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    if hasattr(L, "op_sift_batch_host"):
+        L.op_sift_batch_host.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.op_features_num_images.argtypes = [C.c_void_p]
     L.op_features_count.argtypes = [C.c_void_p, C.c_int]
     L.op_features_offset.restype = C.c_int64
@@ -126,7 +127,8 @@ def lib():
     L.op_features_copy_real.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.op_features_from_host.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
-    L.op_features_adopt_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    if hasattr(L, "op_features_adopt_device"):
+        L.op_features_adopt_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_features_free.argtypes = [C.c_void_p]
     L.op_sift_staged.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.POINTER(C.c_void_p)]
     L.op_sift_dump_free.argtypes = [C.c_void_p]
@@ -144,9 +146,12 @@ def lib():
         L.op_match_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.op_matches_count.argtypes = [C.c_void_p, C.c_int]
         L.op_matches_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.op_matches_copy_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.op_matches_device_list.restype = C.c_void_p
-        L.op_matches_device_list.argtypes = [C.c_void_p]
+        if hasattr(L, "op_matches_copy_all"):
+            L.op_matches_copy_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "op_matches_device_list"):
+            L.op_matches_device_list.restype = C.c_void_p
+        if hasattr(L, "op_matches_device_list"):
+            L.op_matches_device_list.argtypes = [C.c_void_p]
         L.op_matches_total.restype = C.c_int64
         L.op_matches_total.argtypes = [C.c_void_p]
         L.op_matches_free.argtypes = [C.c_void_p]
@@ -157,8 +162,9 @@ def lib():
     L.op_group_ctx.argtypes = [C.c_void_p, C.c_int]
     L.op_sift_batch_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.POINTER(OpImage), C.c_int, C.POINTER(C.c_void_p)]
     L.op_match_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-    L.op_ransac_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                        C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    if hasattr(L, "op_ransac_pairs_multi"):
+        L.op_ransac_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.op_matches_from_host.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.op_ransac_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -169,7 +175,8 @@ def lib():
     L.op_ransac_inlier_count.argtypes = [C.c_void_p, C.c_int]
     L.op_ransac_inliers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.op_ransac_best.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.op_ransac_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    if hasattr(L, "op_ransac_summary"):
+        L.op_ransac_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.op_ransac_free.argtypes = [C.c_void_p]
     L.op_blend_prepare.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.POINTER(OpBlendGeom), C.c_void_p, C.c_void_p]

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-3 pass A: whole GPU suite + default bench (device-resident match lists -> RANSAC, config-5 parity block).
-tag=${1:-r03a}
+# Round-3 full pass: whole GPU suite + default bench (device-resident match lists -> RANSAC, config-5 parity block).
+tag=${1:-r03k}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 ) > gpurun_out/${tag}_pytest.log 2>&1

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--images", type=int, default=38)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 instead: 128 (or --images) synthetic 4000x3000 uint8 images")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     import numpy as np
@@ -30,14 +31,19 @@ def main():
     from openpano_amd import hip, synth
     from openpano_amd.config import PanoConfig
     cfg = PanoConfig()
-    H, W = 867, 1300
-    views = synth.image_set(a.images, H, W, seed=38, overlap=0.45, rows=2, shuffle=True)
     dev = torch.device("cuda", 0)
-    d_imgs = [torch.from_numpy(v).to(dev) for v in views]
+    if a.config5:
+        H, W = 3000, 4000
+        d_imgs = synth.config5_views(range(a.images if a.images != 38 else 128), dev)
+        inputs = [(t.data_ptr(), H, W, "u8") for t in d_imgs]
+    else:
+        H, W = 867, 1300
+        views = synth.image_set(a.images, H, W, seed=38, overlap=0.45, rows=2, shuffle=True)
+        d_imgs = [torch.from_numpy(v).to(dev) for v in views]
+        inputs = [(t.data_ptr(), H, W) for t in d_imgs]
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    inputs = [(t.data_ptr(), H, W) for t in d_imgs]
     libs = ["product"] + list(a.libs)
     out = {}
     for name in libs:
