@@ -121,6 +121,13 @@ def main():
             with open(os.path.join(d, name), "w") as f:
                 f.write(f"// GENERATED by oracle/apply_hooks.py ({var}) from the reference's src/stitch/{name} -- build output, never committed\n")
                 f.write(fn(name, text))
+        if var.startswith("cli_"):
+            # main.cc itself is not edited, but it must be COMPILED from a place where "stitch/stitcher.hh" means the hooked
+            # header: a quoted include looks in the including file's own directory before any -I path, and main.cc
+            # instantiates the StitcherBase constructor template (which detector is built, how the object is laid out)
+            with open(os.path.join(out, var, "main.cc"), "w") as f:
+                f.write(f"// GENERATED by oracle/apply_hooks.py ({var}): the reference's src/main.cc, unedited -- build output, never committed\n")
+                f.write(open(os.path.join(ref, "src", "main.cc")).read())
     print(f"apply_hooks: wrote {', '.join(VARIANTS)} under {out}")
 
 
