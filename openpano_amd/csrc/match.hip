@@ -6,9 +6,9 @@
 // kd-forest's approximate, non-deterministic answers cannot be the parity target.
 //
 // ALL requested image pairs go through two launches of one MFMA sweep kernel (dot-product tiles
-// from two v_mfma_f32_32x32x16_f16 per 16 elements: the row x as a two-term fp16 split, the streamed
-// columns y as one fp16 term, x.y ~ xh.yh + xl.yh, fp32 accumulation: 2^-11-accurate at a fifteenth of
-// the fp32 MFMA's cost per score -- and a running per-row top-4 by score = x.y - |y|^2/2):
+// from three v_mfma_f32_32x32x16_bf16 per 16 elements on a two-term bf16 split of the descriptors
+// -- x = hi + lo, x.y ~ hi.hi + hi.lo + lo.hi, fp32 accumulation: 2^-16-accurate at 5x the rate of
+// the fp32 MFMA -- and a running per-row top-4 by score = x.y - |y|^2/2):
 // a forward sweep of every row of the smaller set, whose epilogue re-scores the ranked
 // candidates with the reference's exact squared L2 and applies the first ratio test, and a
 // reverse sweep over the survivors only, whose epilogue applies the second test.  MFMA results
@@ -122,6 +122,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // One MFMA sweep kernel serves both directions of FeatureMatcher::match:
 //   FWD  rows = every descriptor of the smaller set A, columns = B: exact 2-NN + the first ratio
@@ -134,28 +135,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WorkItem { int pair, rowblock; };
 struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; int ia, ib; };   // ia / ib: image indices of the A / B set (the exact-scan queue is grouped by the image it scans)
 
-constexpr int YP = 68;    // LDS pitch of a Y tile row (floats): 256 bytes of fp16 + one 16-byte slot of rotation -> conflict-free b128
+constexpr int YP = 132;   // LDS pitch of a Y tile row (floats): 16-B slot rotation -> conflict-free b128
 
-// ---- operands of the ranking sweep.  Scores only RANK columns, so the matrix pipe runs on 16-bit operands:
-//   x (the row, resident in VGPRs)  two-term fp16 split  x ~ xh + xl,  xh = fp16(s x), xl = fp16(s x - xh)
-//   y (the columns, streamed)       ONE fp16 term        y ~ yh = fp16(s y)
-// and a score costs two v_mfma_f32_32x32x16_f16 per 16 elements (xh.yh + xl.yh, fp32 accumulation) instead of the three a
-// symmetric two-term split needs -- a third of the matrix work, half of the Y bytes through LDS.  s is a power of two
-// chosen per call from the largest descriptor norm so that every |s v| < 2^14: scaling by it is exact, keeps the
-// products far from fp16's overflow (65504) and the low terms out of its subnormals whatever unit the descriptors
-// come in (RootSIFT: norm 512, s = 16).  What the shortcut costs is accuracy of the KEYS, paid for in the margin E of
-// the epilogue (below): the exact fp32 distances of the reference still decide every match.
-// Every descriptor row is stored as [128 x hi][128 x lo] fp16 (512 B): a set is X in one pair and Y in another.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ int split_scale_log2(unsigned gmax_bits) {
-	// k with 2^k sqrt(gmax) < 2^14: gmax in [2^e, 2^(e+1))  =>  sqrt(gmax) < 2^ceil((e+1)/2)
-	const int e = (int)((gmax_bits >> 23) & 255u) - 127;
-	int k = 14 - ((e + 2) >> 1);
-	return k < -40 ? -40 : (k > 40 ? 40 : k);
+// Two-term bf16 split of every descriptor, row r -> [128 x hi][128 x lo] (512 B): hi = bf16(v)
+// (round to nearest even), lo = bf16(v - hi); v - hi is exact in fp32, so |v - hi - lo| <= 2^-18 |v|.
+// NaN stays NaN in both terms (such a row / column must simply never rank).
+__device__ __forceinline__ unsigned bf16_rn(float v) {
+	const unsigned u = __float_as_uint(v);
+	return v != v ? 0x7fc0u : (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-// pass 1: |row|^2 (16 threads per row, shuffle tree) and the maximum norm of the call (grid-stride loop, one atomic
-// per workgroup: tens of thousands of atomics on one address cost more than the whole pass)
-__global__ void __launch_bounds__(256) k_norms(const float* __restrict__ desc, long long total, float* __restrict__ norms, unsigned* __restrict__ gmax_bits) {
+// The same pass writes |row|^2 (16 threads per row, shuffle tree) and the maximum norm of the call
+// (grid-stride loop, one atomic per workgroup: tens of thousands of atomics on one address cost more
+// than the whole split).
+__global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ desc, long long total, uint4* __restrict__ split,
+		float* __restrict__ norms, unsigned* __restrict__ gmax_bits) {
 	__shared__ unsigned s_max[4];
 	unsigned mymax = 0u;                                       // norms are >= 0: their bit patterns order like the values
 	const long long nthreads = total * 16, stride = (long long)gridDim.x * 256;
@@ -173,33 +166,21 @@ __global__ void __launch_bounds__(256) k_norms(const float* __restrict__ desc, l
 #pragma unroll
 		for (int d = 1; d < 16; d <<= 1) sq += __shfl_xor(sq, d);
 		if (live && c == 0) norms[row] = sq;
-		if (sq == sq && sq < 3.0e38f) mymax = max(mymax, __float_as_uint(sq));   // a NaN / infinite descriptor must not poison the scale and the margin of every row
+		if (sq == sq) mymax = max(mymax, __float_as_uint(sq));   // a NaN descriptor must not poison the margin of every row
+		if (!live) continue;
+		unsigned hi[8], lo[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) { hi[e] = bf16_rn(v[e]); lo[e] = bf16_rn(v[e] - __uint_as_float(hi[e] << 16)); }
+		uint4 H, L;
+		H.x = hi[0] | (hi[1] << 16); H.y = hi[2] | (hi[3] << 16); H.z = hi[4] | (hi[5] << 16); H.w = hi[6] | (hi[7] << 16);
+		L.x = lo[0] | (lo[1] << 16); L.y = lo[2] | (lo[3] << 16); L.z = lo[4] | (lo[5] << 16); L.w = lo[6] | (lo[7] << 16);
+		split[row * 32 + c] = H; split[row * 32 + 16 + c] = L;
 	}
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, d));
 	if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mymax;
 	__syncthreads();
 	if (threadIdx.x == 0) atomicMax(gmax_bits, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-}
-// pass 2: hi = fp16(s v) (round to nearest even), lo = fp16(s v - hi); s v - hi is exact in fp32, so
-// |s v - hi - lo| <= 2^-22 |s v|.  NaN stays NaN in both terms (such a row / column simply never ranks).
-__global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ desc, long long total, uint4* __restrict__ split, const unsigned* __restrict__ gmax_bits) {
-	const float sc = ldexpf(1.f, split_scale_log2(*gmax_bits));
-	const long long nthreads = total * 16;
-	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-	if (i >= nthreads) return;
-	const long long row = i >> 4; const int c = (int)(i & 15);
-	const f32x4* p = (const f32x4*)(desc + row * 128 + c * 8);
-	const f32x4 a = p[0], b = p[1];
-	const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-	f16x8 H, L;
-#pragma unroll
-	for (int e = 0; e < 8; ++e) {
-		const float sv = v[e] * sc;
-		const _Float16 h = (_Float16)sv;
-		H[e] = h; L[e] = (_Float16)(sv - (float)h);
-	}
-	split[row * 32 + c] = __builtin_bit_cast(uint4, H); split[row * 32 + 16 + c] = __builtin_bit_cast(uint4, L);
 }
 
 constexpr int NK = 4;      // kept entries per lane half (descending); a half whose NK entries all tie within the error margin sends its row to the exact full scan
@@ -294,7 +275,7 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 }
 
 // One workgroup = 128 rows of X (4 waves x 32 rows, the split X fragments resident in VGPRs) against
-// all of Y, whose hi terms stream through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
+// all of Y, whose split rows stream through LDS 32 columns at a time.  D = Ytile * X^T so that every lane ends up
 // holding 16 scores of ONE X row (C/D layout: col = lane&31), which makes the running top-4 a
 // purely per-lane update (on keys, above); the two lane halves of a row (columns i & 4 == 0 / != 0 of
 // every tile) exchange their lists once at the end.  The accumulators start from -|y|^2/2, so the MFMA
@@ -305,8 +286,8 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 // lower half walks t = 0..15, hands its four partial sums to the upper half, which walks
 // t = 16..31 -- candidates are software-pipelined through the two halves.  The candidate set is
 // provably complete: every column whose key is within E of the row's 2nd best is re-scored, where E
-// bounds twice the worst-case error of a key (the dropped x.(y - yh) <= 2^-11 |x||y|, the split residual of x,
-// 257 fp32 accumulations, the fp32 norm, the 4 slot bits) plus the rounding of the reference's own fp32
+// bounds twice the worst-case error of a key (dropped split terms 3 * 2^-18, 385 fp32
+// accumulations, the fp32 norm, the 4 slot bits) plus the rounding of the reference's own fp32
 // distance; a row one of whose halves has all 4 kept entries inside the margin is queued for an
 // exact full scan instead.
 template <bool REV>
@@ -353,10 +334,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	// Four 16-byte blocks per thread and tile, in four named registers (an array here ended up in scratch
 	// memory once the loads lost their predication).  No exec-mask branches: rows past the end of Y
 	// re-read its last row, their columns cannot rank because their |y|^2/2 is FLT_MAX.
-	const float s2 = ldexpf(1.f, 2 * split_scale_log2(*S.gmax_bits));      // the scores live in units of s^2
-	const float nyh_scale = -0.5f * s2;
-	uint4 st0, st1; float stage_ny = 0.f; bool stage_pad = false;
-	const int f_yr = tid >> 4, f_c4 = tid & 15;          // hi half of a split row = 16 blocks: block e = tid + 256 r  ->  row f_yr + 16 r, column block f_c4
+	uint4 st0, st1, st2, st3; float stage_ny = 0.f; bool stage_pad = false;
+	const int f_yr = tid >> 5, f_c4 = tid & 31;          // block e = tid + 256 r  ->  row f_yr + 8 r, column block f_c4
 	// 32-bit byte offsets from the (uniform) base of the Y split: the loads take the SGPR-base + VGPR-offset form,
 	// a row clamp is one v_min on the offset (op_match_pairs refuses sets of 4 M descriptors and more)
 	const char* ys_base = (const char*)YS;
@@ -364,9 +343,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	const unsigned f_first = (unsigned)f_yr * 512u + (unsigned)f_c4 * 16u;
 	auto fetch_tile = [&](int t) {
 		const unsigned o0 = f_first + (unsigned)t * 16384u;
-		const unsigned g0 = o0 < f_last ? o0 : f_last, g1 = o0 + 8192u < f_last ? o0 + 8192u : f_last;
+		const unsigned g0 = o0 < f_last ? o0 : f_last, g1 = o0 + 4096u < f_last ? o0 + 4096u : f_last,
+				g2 = o0 + 8192u < f_last ? o0 + 8192u : f_last, g3 = o0 + 12288u < f_last ? o0 + 12288u : f_last;
 		st0 = *(const uint4*)(ys_base + g0);
 		st1 = *(const uint4*)(ys_base + g1);
+		st2 = *(const uint4*)(ys_base + g2);
+		st3 = *(const uint4*)(ys_base + g3);
 		// the raw |y|^2 only: any arithmetic on it here would wait for the load at the top of the iteration
 		const int gy = t * 32 + (tid & 31);
 		stage_ny = ny[gy < ky ? gy : ky - 1];
@@ -375,8 +357,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	auto commit_tile = [&](int buf) {
 		float* d = &s_y[buf][f_yr * YP + f_c4 * 4];
 		*(uint4*)(d) = st0;
-		*(uint4*)(d + 16 * YP) = st1;
-		if (tid < 32) s_nyh[buf][tid] = stage_pad ? -FLT_MAX : nyh_scale * stage_ny;   // -s^2 |y|^2 / 2: the accumulators START from it; padded columns can never rank
+		*(uint4*)(d + 8 * YP) = st1;
+		*(uint4*)(d + 16 * YP) = st2;
+		*(uint4*)(d + 24 * YP) = st3;
+		if (tid < 32) s_nyh[buf][tid] = stage_pad ? -FLT_MAX : -0.5f * stage_ny;   // -|y|^2/2: the accumulators START from it; padded columns can never rank
 	};
 
 	fetch_tile(0);
@@ -392,7 +376,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		const int buf = t & 1;
 		if (t + 1 < ntiles) fetch_tile(t + 1);
 		STAMP(0);
-		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // the 16 16-byte blocks of tile row j's hi term
+		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
 		// the accumulators start from -|y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h (four
 		// 16-byte LDS reads straight into the accumulator registers): the MFMA chain ends on the scores
 		f32x16 acc;
@@ -405,10 +389,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		// DESIGN.md section 6)
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
-			const f16x8 ah = __builtin_bit_cast(f16x8, yrow[2 * kb + h]);
-			const f16x8 bh = __builtin_bit_cast(f16x8, xh[kb]), bl = __builtin_bit_cast(f16x8, xl[kb]);
-			acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-			acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
+			const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[kb]), bl = __builtin_bit_cast(bf16x8, xl[kb]);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
 #if OP_MATCH_EXPERIMENT == 9
 		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
@@ -449,10 +434,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	// Only a half whose four entries ALL sit inside the margin sends the row to the exact full scan (four
 	// near-ties in one half: an order of magnitude rarer than four in the row).
 	const float gmax = __uint_as_float(*S.gmax_bits);
-	// E = twice the worst-case error of a key plus the rounding of the reference's own fp32 distance, in the keys' units
-	// (s^2): the one-term y drops x.(y - yh) <= 2^-11 |x||y|, the two-term x leaves 2^-22 |x||y|, 257 fp32 accumulations
-	// of exact fp16 x fp16 products starting from -|y|^2/2, the fp32 norm, the 4 slot bits
-	const float E = 5.5e-4f * s2 * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
+	const float E = 8.2e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);   // 8e-5 for the MFMA scores + 2 * 2^-20 for the keys' slot bits
 	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];            // [half][NK] contiguous
 	const float second = fmaxf(fminf(ms[0], ms[NK]), fmaxf(ms[1], ms[NK + 1]));      // 2nd largest key of the row (invalid entries rank below every real one)
 	const float thr = second - E;
@@ -818,9 +800,8 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		const WorkItem* d_work = (const WorkItem*)(arena + o_up + sizeof(PairDesc) * npairs);
 		{
 			ProfScope ps(ctx, "matcher norms");
-			hipLaunchKernelGGL(k_norms, dim3((unsigned)std::min<long long>((total * 16 + 255) / 256, 1024)), dim3(256), 0, st, fv.desc, total,
-					(float*)(arena + o_norms), (unsigned*)ctrl);
-			hipLaunchKernelGGL(k_split_f16, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, fv.desc, total, (uint4*)(arena + o_split), (const unsigned*)ctrl);
+			hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)std::min<long long>((total * 16 + 255) / 256, 1024)), dim3(256), 0, st, fv.desc, total,
+					(uint4*)(arena + o_split), (float*)(arena + o_norms), (unsigned*)ctrl);
 			MCHK(hipGetLastError());
 		}
 		if (!work.empty()) {
