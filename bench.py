@@ -463,8 +463,10 @@ def main():
     dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
     # algorithmic HBM bytes per launch (DESIGN.md "kernels"), per image:
     alg = {
-        # fused scale space + extrema scan: grey in; 6 DoG + 4 Gaussian planes out (DESIGN.md section 3;
-        # the scan runs on the DoG layers while they are in LDS and mag/ort are never materialised)
+        # fused scale space + extrema scan.  ALGORITHMIC bytes as apportioned from SURVEY 8(d) since round 1: grey in, the six DoG
+        # planes out (24 P, read back by the refinement) and what stands in for the reference's mag / ort planes (16 P:
+        # Gaussian scales 1-4).  The kernel as built moves LESS than that: only the Gaussian stack reaches HBM (4 P in,
+        # 24 P out = 28 P) -- `traffic` / `achieved_traffic` next to it say what actually crossed.
         "build pyramid": 4 * P + 24 * P + 16 * P,
         "resize + octave grey": 12 * H * W + 4 * P,                      # source in, grey octave bases out (working image stays in LDS)
         "sift descriptor": (k_rank / max(nimg, 1)) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
@@ -475,8 +477,14 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
+            import hashlib
             pmc = json.load(open(pmc_path))
-            pmc_src = f"replayed from profiles/pmc_latest.json ({pmc.get('_meta', {}).get('tag', 'untagged')}; rocprofv3 --pmc passes of scripts/gpu_pmc.sh, not collected in this run)"
+            lib_hash = hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16]
+            if pmc.get("_meta", {}).get("lib_sha256_16") != lib_hash:
+                log(f"profiles/pmc_latest.json was collected with another build of the library ({pmc.get('_meta', {}).get('lib_sha256_16')} != {lib_hash}): roofline.traffic dropped")
+                pmc = {}
+            else:
+                pmc_src = f"replayed from profiles/pmc_latest.json ({pmc.get('_meta', {}).get('tag', 'untagged')}; rocprofv3 --pmc passes of scripts/gpu_pmc.sh over THIS build of the library, lib_sha256_16 {lib_hash}; not collected in this run)"
         except Exception:
             pmc = {}
 
@@ -489,6 +497,8 @@ def main():
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
                 "traffic": tr,      # rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE) * 1024
                 "traffic_source": pmc_src if tr is not None else None,
+                "achieved_traffic": (tr / dur_s / 1e9) if tr else None,          # the bytes that really crossed HBM / the same time
+                "traffic_over_algorithmic": (tr / (b * nimg)) if (tr and b) else None,
                 "algorithmic_bytes_per_launch": b * nimg if b else None, "avg_launch_ms": stage_ms[name]}
 
     roofline = stage_roofline(dominant) if dominant is not None else None

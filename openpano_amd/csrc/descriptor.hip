@@ -324,8 +324,9 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		hist[lane] = acc0;
 		hist[lane + 64] = acc1;
 		__syncthreads();
-		float sum = 0.f;
-		for (int i = 0; i < 128; ++i) sum += hist[i];
+		float sum = 0.f;            // the reference's sequential fp32 sum (sift.cc:39-40), 16 bytes per LDS read
+#pragma unroll 4
+		for (int i = 0; i < 32; ++i) { const f32x4 q = ((const f32x4*)hist)[i]; sum += q.x; sum += q.y; sum += q.z; sum += q.w; }
 		float* out = desc + kk * 128;
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {

@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round-3 evidence pass for the CURRENT build of the library (everything lands under gpurun_out/<tag>_*; copy what is kept to profiles/):
+#   1 whole GPU suite                         -> <tag>_pytest.log
+#   2 default bench (parity + CPU baselines)  -> <tag>_bench.json
+#   3 rocprofv3 --kernel-trace --stats of a config-4 bench run (numpy-made inputs: no torch kernels in the table) -> <tag>_prof/
+#   4 the four PMC passes of scripts/gpu_pmc.sh (pmc json carries the library hash; bench.py replays traffic only for the same hash)
+#   5 one-rank RCCL run (OPENPANO_FORCE_DIST=1): the exchange / gather code on the nccl backend
+#   6 micro-benchmarks the matcher section of DESIGN.md quotes: mfma_power, mfma_valu_overlap, the sweep's phase trace
+# Usage: scripts/gpu_r03_evidence.sh <tag> [sections, default "1 2 3 4 5 6"]
+tag=${1:-r03}; what=${2:-"1 2 3 4 5 6"}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+has() { [[ " $what " == *" $1 "* ]]; }
+if has 1; then
+  ( time timeout 1500 python -m pytest tests -m gpu -q --durations=6 ) > gpurun_out/${tag}_pytest.log 2>&1
+  echo "[pytest rc=$?]"; tail -12 gpurun_out/${tag}_pytest.log
+fi
+if has 2; then
+  ( time timeout 900 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+  echo "[bench rc=$?]"; tail -4 gpurun_out/${tag}_bench.err
+fi
+if has 3; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o sift -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 \
+    > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err
+  f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv && cut -c1-170 "$f" | head -22
+fi
+if has 4; then
+  bash scripts/gpu_pmc.sh ${tag} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 2>&1 | tail -30
+fi
+if has 5; then
+  ( OPENPANO_FORCE_DIST=1 timeout 600 python bench.py --steps 10 --no-cpu-baseline --no-e2e --no-blend --no-ingest ) > gpurun_out/${tag}_bench_forcedist.json 2> gpurun_out/${tag}_bench_forcedist.err
+  echo "[forcedist rc=$?]"
+fi
+if has 6; then
+  for b in mfma_power mfma_valu_overlap; do
+    [ -x scripts/ubench/$b ] && ( echo "== scripts/ubench/$b"; timeout 120 scripts/ubench/$b ) > gpurun_out/${tag}_ubench_$b.txt 2>&1
+    tail -8 gpurun_out/${tag}_ubench_$b.txt
+  done
+  [ -f openpano_amd/variants/libopenpano_hip_match9.so ] && ( OPENPANO_TRACE_LIB=match9 timeout 600 python scripts/match_trace.py ) > gpurun_out/${tag}_match_trace.txt 2>&1
+  grep "^K=\|residents" gpurun_out/${tag}_match_trace.txt | cut -c1-400
+fi
+python - <<PY
+import json
+for name in ("bench", "bench_forcedist"):
+    try:
+        d = json.loads(open("gpurun_out/${tag}_%s.json" % name).read().strip().splitlines()[-1])
+    except Exception as e:
+        print(name, "not parsed:", e); continue
+    print(name, "value %.4g ms/step %.4f" % (d["value"], d["ms_per_step"]), d["stage_ms"], "frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
+    m = d.get("match") or {}
+    print("  match", m.get("ms_per_step"), m.get("stage_ms"), "allgather", m.get("descriptor_allgather_ms"), "gather", m.get("match_results_gather_ms"))
+    print("  ransac", (d.get("ransac") or {}).get("ms_per_step"), (d.get("ransac") or {}).get("stage_ms"))
+    if "config5" in d: print("  config5", d["config5"]["phase_ms"], d["config5"]["match_roofline"]["frac"], (d["config5"].get("parity") or {}).get("ok"))
+    if "blend" in d: print("  blend", {k: (round(v["ms_per_blend"], 3), round(v["roofline"]["frac"], 3)) for k, v in d["blend"].items()})
+    if "protocol" in d: print("  protocol", d["protocol"]["ms_per_step_mat32f"], d["protocol"]["ms_per_step_uint8"])
+    if d.get("cpu_baseline"): print("  cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], "gpu/cpu", d.get("gpu_over_cpu"), "parity", d.get("parity_checked"))
+PY
