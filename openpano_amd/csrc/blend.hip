@@ -146,7 +146,12 @@ __global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, const Blend
 		float4* __restrict__ cur, unsigned char* __restrict__ mask, float* __restrict__ out, unsigned char* __restrict__ tmask, int H, int W) {
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (i >= H || j >= W) return;
+	// The target is as large as the largest bottom-right ROI coordinate (blender.cc:21) while ROIs are inclusive
+	// (blender.hh:19-27): an ROI's last column / row can lie ONE pixel outside the target.  The reference still builds
+	// that pixel of the image's level 0 (it feeds the blurs) but its weight-map walk never visits it, so it keeps its
+	// own weight; the grid therefore covers (H + 1) x (W + 1) and only pixels inside the target take part in the map.
+	if (i > H || j > W) return;
+	const bool inside = i < H && j < W;
 	const double cx = (double)j * g.resx + g.minx;
 	const double cy = (double)i * g.resy + g.miny;
 	double hx, hy, hz;
@@ -166,12 +171,13 @@ __global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, const Blend
 			const double x = ox / (double)im.w - 0.5, y = oy / (double)im.h - 0.5;
 			const double v = (0.5 - fabs(x)) * (0.5 - fabs(y));
 			const float w = (float)((v > 0.0 ? v : 0.0) + 1e-6);
-			px = make_float4(col[0], col[1], col[2], 0.f);
+			px = make_float4(col[0], col[1], col[2], inside ? 0.f : w);
 			if (w > mx) { mx = w; maxe = e; }                     // multiband.cc:133-137
 		}
 		cur[e] = px;
 		mask[e] = ok ? 0 : 1;
 	}
+	if (!inside) return;
 	if (maxe >= 0) ((float*)&cur[maxe])[3] = 1.f;
 	const long long pe = (long long)i * W + j;
 	out[pe * 3] = -1.f; out[pe * 3 + 1] = -1.f; out[pe * 3 + 2] = -1.f;
@@ -229,9 +235,14 @@ __global__ void __launch_bounds__(256) k_mb_blur(const BlendImg* __restrict__ im
 //   row pass     the column-pass row goes to LDS (double buffered: one barrier per row), thread = output
 //                column reads its 2C+1 neighbours as b128 and applies the same taps in order.
 // The intermediate plane never reaches HBM; a source pixel is read once per band (+ the segment halo).
-template <int CT>
+// FIRST (level 0 -> 1): the band of level 0 (multiband.cc:75-110) is written here as well.  After the
+// winner-takes-all map exactly one image has weight 1 at a target pixel and every other one 0, so the reference's
+// sum over images has a single term, (cur - next) * 1 / 1: the winner's thread holds cur (its column window) and next
+// (just computed) and stores the band into the untouched target -- the level-0 pass of k_mb_accumulate (a read of
+// every image's ROI plane) disappears.
+template <int CT, bool FIRST>
 __global__ void __launch_bounds__(256) k_mb_blur_fused(const BlendImg* __restrict__ imgs, BlurTaps taps,
-		const float4* __restrict__ src, float4* __restrict__ dst) {
+		const float4* __restrict__ src, float4* __restrict__ dst, float* __restrict__ target, unsigned char* __restrict__ tmask, int H, int W) {
 	constexpr int NT = 2 * CT + 1;          // taps
 	constexpr int TWO = 256 - 2 * CT;       // output columns of a band
 	constexpr int SEG = 4 * NT;             // rows of a segment (a whole number of window rotations)
@@ -279,6 +290,18 @@ __global__ void __launch_bounds__(256) k_mb_blur_fused(const BlendImg* __restric
 					o.w += s.w * kv; o.x += s.x * kv; o.y += s.y * kv; o.z += s.z * kv;
 				}
 				out[(long long)r * rw + x] = o;
+				if (FIRST) {
+					const float4 cc = v[(u + CT) % NT];              // level-0 pixel (r, x): the centre tap's row of this thread's own column
+					const int ti = im.y0 + r, tj = im.x0 + x;
+					if (cc.w > 0 && ti < H && tj < W) {              // the winner (weight 1); a masked pixel has weight 0
+						float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
+						s0 += (cc.x - o.x) * cc.w; s1 += (cc.y - o.y) * cc.w; s2 += (cc.z - o.z) * cc.w; wsum += cc.w;
+						s0 /= wsum; s1 /= wsum; s2 /= wsum;
+						const long long pe = (long long)ti * W + tj;
+						target[pe * 3] = s0; target[pe * 3 + 1] = s1; target[pe * 3 + 2] = s2;
+						tmask[pe] = 1;
+					}
+				}
 			}
 		}
 	}
@@ -666,10 +689,11 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		BCHK(pool_alloc((void**)&tmask, (size_t)H * W)); fr.v.push_back(tmask);
 		const dim3 rgrid((unsigned)((max_roi + 255) / 256), n);
 		{ ProfScope ps(ctx, "multiband first level");
-		  hipLaunchKernelGGL(k_mb_first_fused, cgrid, dim3(256), 0, st, bg, d_imgs, n, cur, mask, cv->data, tmask, H, W);
+		  hipLaunchKernelGGL(k_mb_first_fused, dim3((W + 1 + 63) / 64, (H + 1 + 3) / 4), dim3(256), 0, st, bg, d_imgs, n, cur, mask, cv->data, tmask, H, W);
 		  BCHK(hipGetLastError()); }
 		for (int level = 0; level < L; ++level) {
 			const int is_last = (level == L - 1);
+			bool band_done = false;              // level 0's band written by the fused blur
 			if (!is_last) {
 				ProfScope ps(ctx, "multiband blur");
 				BlurTaps taps; memset(&taps, 0, sizeof(taps));
@@ -681,15 +705,18 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 					unsigned items = 1;
 					for (int k = 0; k < n; ++k)
 						items = std::max(items, (unsigned)(((h_imgs[k].rw + two - 1) / two) * ((h_imgs[k].rh + segr - 1) / segr)));
-					if (C == 6) hipLaunchKernelGGL((k_mb_blur_fused<6>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt);
-					else hipLaunchKernelGGL((k_mb_blur_fused<9>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt);
+					band_done = level == 0;
+					if (C == 6 && level == 0) hipLaunchKernelGGL((k_mb_blur_fused<6, true>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
+					else if (C == 6) hipLaunchKernelGGL((k_mb_blur_fused<6, false>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
+					else if (level == 0) hipLaunchKernelGGL((k_mb_blur_fused<9, true>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
+					else hipLaunchKernelGGL((k_mb_blur_fused<9, false>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
 				} else {
 					hipLaunchKernelGGL((k_mb_blur<true, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
 					hipLaunchKernelGGL((k_mb_blur<false, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
 				}
 				BCHK(hipGetLastError());
 			}
-			{ ProfScope ps(ctx, "multiband band");
+			if (!band_done) { ProfScope ps(ctx, "multiband band");
 			  hipLaunchKernelGGL(k_mb_accumulate, cgrid, dim3(256), 0, st, d_imgs, n, cur, nxt, mask, cv->data, tmask, H, W, is_last);
 			  BCHK(hipGetLastError()); }
 			std::swap(cur, nxt);
