@@ -288,14 +288,17 @@ class ShardedJob:
         return sum(self.counts)
 
     def exchange(self):
+        # the previous table goes first: its buffers are what the allocator hands out again for the new one (a second
+        # generation of a 265 MB table costs two device allocations of several milliseconds each)
+        if self.tab is not None:
+            self.e.free(self.tab); self.tab = None
+        self._keep = None
         if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the header collective really runs
             # slices arrive in place, in GLOBAL image order: pair (i, j), its match list and its RANSAC draw
             # sequence are those of the single-rank job whatever the world size
             gdesc, gcoor, gcounts = allgatherv_features(self.desc, self.coor, self.counts, self.n, self.group)
         else:
             gdesc, gcoor, gcounts = self.desc, self.coor, self.counts
-        if self.tab is not None:
-            self.e.free(self.tab)
         self._keep = (gdesc, gcoor)
         self.tab = self.e.table(gdesc, gcoor, gcounts)
         self.gcounts = gcounts

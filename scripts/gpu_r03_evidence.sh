@@ -20,12 +20,12 @@ if has 2; then
   echo "[bench rc=$?]"; tail -4 gpurun_out/${tag}_bench.err
 fi
 if has 3; then
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o sift -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 \
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o sift -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err
   f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv && cut -c1-170 "$f" | head -22
 fi
 if has 4; then
-  bash scripts/gpu_pmc.sh ${tag} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 2>&1 | tail -30
+  bash scripts/gpu_pmc.sh ${tag} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest 2>&1 | tail -30
 fi
 if has 5; then
   ( OPENPANO_FORCE_DIST=1 timeout 600 python bench.py --steps 10 --no-cpu-baseline --no-e2e --no-blend --no-ingest ) > gpurun_out/${tag}_bench_forcedist.json 2> gpurun_out/${tag}_bench_forcedist.err
