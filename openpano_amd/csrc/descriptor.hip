@@ -23,9 +23,6 @@
 // rotated-square tests are enumerated (a conservative interval), the exact tests decide.
 #include "internal.hpp"
 #include "devmath.hpp"
-#ifndef OP_DESC_EXPERIMENT
-#define OP_DESC_EXPERIMENT 0
-#endif
 
 namespace {
 
@@ -164,25 +161,11 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				const int gi = S.q_gi[qi];
 				const float x_rot = S.q_xr[qi], y_rot = S.q_yr[qi];
 				const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
-#if OP_DESC_EXPERIMENT == 4
-				const float gdy = 0.f, gdx = 0.f; (void)gi;
-#else
 				const float gdy = g_img[gi + w] - g_img[gi - w];
 				const float gdx = g_img[gi + 1] - g_img[gi - 1];
-#endif
-#if OP_DESC_EXPERIMENT == 1       // timing experiment only: no transcendental twins
-				const float now_mag = gdx + gdy;
-				float now_ort = fabsf(gdy - gdx) + 3.f;
-				float weight = x_rot * 0.1f + 1.f;
-#elif OP_DESC_EXPERIMENT == 4     // timing experiment only: no gathers
-				const float now_mag = opdev::hypotf_glibc(x_rot, y_rot);
-				float now_ort = opdev::fast_atan_plus_pi(y_rot, x_rot);
-				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom, S.exptab);
-#else
 				const float now_mag = opdev::hypotf_glibc(gdx, gdy);
 				float now_ort = opdev::fast_atan_plus_pi(gdy, gdx);
 				float weight = opdev::expf_glibc(-(x_rot * x_rot + y_rot * y_rot) / exp_denom, S.exptab);
-#endif
 				weight = weight * now_mag;
 				now_ort -= ort;
 				if (now_ort < 0) now_ort += pi2;
@@ -212,11 +195,6 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			// adjacent orientation bins h0 and h0 + 1: ONE mask bit per (cell, h0) records both (4 LDS atomics
 			// per sample instead of 8), the contributors of bin (cell, k) are mask[cell][k] (their first value)
 			// and mask[cell][k - 1] (their second) -- disjoint sets, merged in lane = sample order.
-#if OP_DESC_EXPERIMENT == 2       // timing experiment only: no ordering machinery
-			for (int u = 0; u < 4; ++u) { acc0 += vA[u] + vB[u]; acc1 += (float)cb[u]; }
-			qhead = (qhead + n) & (QCAP - 1); qn -= n;
-			return;
-#endif
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
 				if (cb[u] >= 0) atomicOr(&S.mask[cb[u] + hq], 1ULL << lane);
@@ -254,11 +232,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				const int na = (__popcll(S.mask[lane] | S.mask[bprev]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64] | S.mask[bprev + 64]) + 3) & ~3;
 				const f32x4* la = (const f32x4*)&S.sorted[S.off[lane]];
 				const f32x4* lb = (const f32x4*)&S.sorted[S.off[lane + 64]];
-#if OP_DESC_EXPERIMENT == 7       // timing experiment only: one accumulation round
-				const int T = 4;
-#else
 				const int T = wave_max_i(na > nb ? na : nb);
-#endif
 				for (int e = 0; e < T; e += 8) {
 					f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
 					if (e < na) a0 = la[e >> 2];
@@ -309,14 +283,9 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				S.q_gi[qi] = gi; S.q_xr[qi] = x_rot; S.q_yr[qi] = y_rot;
 			}
 			qn += __popcll(mask);
-#if OP_DESC_EXPERIMENT == 3       // timing experiment only: scan without the batches
-			if (qn >= 64) { qhead = (qhead + 64) & (QCAP - 1); qn -= 64; acc0 += x_rot; }
-		}
-#else
 			if (qn >= 64) { __syncthreads(); process_batch(64); }
 		}
 		if (qn > 0) { __syncthreads(); process_batch(qn); }
-#endif
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
 		// (the histogram reuses the list buffer: 8 KB of LDS per workgroup = 20 workgroups, 5 waves per SIMD)

@@ -14,9 +14,6 @@
 // reverse sweep over the survivors only, whose epilogue applies the second test.  MFMA results
 // only RANK candidates; the reference's float arithmetic decides every match.
 #include "internal.hpp"
-#ifndef OP_MATCH_EXPERIMENT
-#define OP_MATCH_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
-#endif
 #include <cfloat>
 #include <cstring>
 #include <memory>
@@ -105,18 +102,7 @@ op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::ve
 	return m;
 }
 
-#if OP_MATCH_EXPERIMENT == 9
-__device__ unsigned long long g_match_timers[10];   // 0-4 phases, 5 tiles, 6 epilogue cycles, 7 workgroups, 8 / 9 workgroup lifetime in 100 MHz ticks / shader cycles
-__device__ int g_occ[2048];                         // workgroups resident per CU right now (key: XCC, SE, SH, CU of HW_ID)
-__device__ unsigned long long g_occ_hist[8];         // how many workgroups found c = 1..7 residents (themselves included) on their CU at start
-__device__ __forceinline__ int occ_key() {
-	const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_HW_ID, HW_REG_XCC_ID
-	return (int)(((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u));
-}
-#define STAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
-#else
 #define STAMP(k) do { } while (0)
-#endif
 
 namespace {
 
@@ -366,12 +352,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	fetch_tile(0);
 	commit_tile(0);
 	__syncthreads();
-#if OP_MATCH_EXPERIMENT == 9
-	unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-	const unsigned long long wall0 = wall_clock64(), cyc0 = tlast;
-	const int okey = occ_key();
-	if (tid == 0) { const int c = atomicAdd(&g_occ[okey], 1) + 1; atomicAdd(&g_occ_hist[c < 7 ? c : 7], 1ULL); }
-#endif
 	for (int t = 0; t < ntiles; ++t) {
 		const int buf = t & 1;
 		if (t + 1 < ntiles) fetch_tile(t + 1);
@@ -395,9 +375,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
 		}
-#if OP_MATCH_EXPERIMENT == 9
-		asm volatile("s_nop 0" :: "v"(acc[15]));          // the last MFMA result is in its register
-#endif
 		STAMP(1);
 		// lane holds D[i][j] for i = (reg&3) + 8*(reg>>2) + 4*h : 16 Y columns of X row j
 		const float old_keys[NK] = {ts[0], ts[1], ts[2], ts[3]};
@@ -412,9 +389,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		__syncthreads();
 		STAMP(4);
 	}
-#if OP_MATCH_EXPERIMENT == 9
-	if (tid == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&g_match_timers[k], tacc[k]); atomicAdd(&g_match_timers[5], (unsigned long long)ntiles); tlast = clock64(); }
-#endif
 	// (tile, slot) -> column: slot reg of lane half h is column (reg & 3) + 8 (reg >> 2) + 4 h of its tile; never-filled
 	// entries (tile -1) and the padded columns of the last tile (score -FLT_MAX, they rank above nothing real) are no candidates
 #pragma unroll
@@ -510,9 +484,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		} else if (REV) finish_reverse(S, pd, wk.pair, a_row, next_min);
 		else finish_forward(S, pd, wk.pair, a_row, mn, next_min, min_idx);
 	}
-#if OP_MATCH_EXPERIMENT == 9
-	if (tid == 0) { atomicAdd(&g_match_timers[6], clock64() - tlast); atomicAdd(&g_match_timers[7], 1ULL); atomicAdd(&g_match_timers[8], wall_clock64() - wall0); atomicAdd(&g_match_timers[9], clock64() - cyc0); atomicSub(&g_occ[okey], 1); }
-#endif
 }
 
 // rows whose NK ranked candidates all fell inside the error margin (near-duplicate descriptors):
@@ -833,9 +804,6 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		hs.reset(); hs.reset(new HostScope(ctx, "matcher wait + counts (host)"));
 		MCHK(hipStreamSynchronize(st));
 		resolve_profile(ctx);                            // (the sort below stays pending until the next resolve: no second wait)
-#if OP_MATCH_EXPERIMENT == 9
-		fprintf(stderr, "[match trace] exact-scan rows: forward %d, reverse %d\n", h_res[0], h_res[1]);
-#endif
 		if (!work.empty()) {
 			if (h_res[0] > slow_cap || h_res[1] > slow_cap) {
 				// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
@@ -865,19 +833,6 @@ done:
 	return OP_OK;
 }
 
-#if OP_MATCH_EXPERIMENT == 9
-// timing experiment only: cycles of wave 0 per phase, summed over all workgroups since the last read
-int op_debug_match_timers(unsigned long long* out) {
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_timers), sizeof(unsigned long long) * 10) != hipSuccess) return -1;
-	unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	return hipMemcpyToSymbol(HIP_SYMBOL(g_match_timers), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-int op_debug_match_occupancy(unsigned long long* out) {
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_occ_hist), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-	unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	return hipMemcpyToSymbol(HIP_SYMBOL(g_occ_hist), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out) {
 	if (!idx_pairs || !counts || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_matches_from_host: bad argument");

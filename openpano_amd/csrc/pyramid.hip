@@ -510,18 +510,12 @@ __device__ __forceinline__ f32x2 pk_hi(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mo
 // offsets, and L2 no longer merges the partial lines at wave and band seams before they reach HBM)
 
 // 26-neighbour test on the DoG ring (extrema.cc:181-207): slot = ring row of the centre
-#ifndef OP_PYR_EXPERIMENT
-#define OP_PYR_EXPERIMENT 0      // timing experiments only (scripts/build_variant.sh); 0 in the product build
-#endif
 __device__ __forceinline__ float max3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float min3f(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // The reference clears `max` on any neighbour v >= center - judge and `min` on any v <= center + judge: with the largest
 // and the smallest of the 26 neighbours (v_max3 / v_min3 skip NaNs like the element-wise comparisons do) that is two
 // comparisons, written negated so that a NaN on either side leaves the flag set as the reference's loop does.
 __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int slot, int L, int hc, float judge) {
-#if OP_PYR_EXPERIMENT == 6 || OP_PYR_EXPERIMENT == 7
-	return sD[0][L][hc] > judge * 1000.f;     // timing experiment: smaller ring, no real test
-#endif
 	const float center = sD[slot][L][hc];
 	const float cmp1 = center - judge, cmp2 = center + judge;
 	float v[26]; int n = 0;
@@ -543,30 +537,14 @@ __device__ __forceinline__ bool ring_extremum(const float (*sD)[6][RW_H], int sl
 	return !(mx >= cmp1) || !(mn <= cmp2);
 }
 
-#if OP_PYR_EXPERIMENT == 9
-__device__ unsigned long long g_pyr_timers[12];   // 0-6 phases, 7 prologue, 8 lifetime, 9 workgroups, 10 steps
-#define PSTAMP(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } } while (0)
-#else
-#define PSTAMP(k) do { } while (0)
-#endif
 __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restrict__ raw, int* __restrict__ raw_count, int cap) {
 	__shared__ f32x2 sV[3][2][256];          // column-pass results [sigma pair][row of the pair][column]
 	__shared__ float sGrey[2][256];
-#if OP_PYR_EXPERIMENT == 6
-#define OP_RING_ROWS 2
-#elif OP_PYR_EXPERIMENT == 7
-#define OP_RING_ROWS 1
-#else
 #define OP_RING_ROWS 4
-#endif
 	__shared__ float sD[OP_RING_ROWS][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
 	__shared__ unsigned short sQ[RW_QCAP];
 	__shared__ int sQn[2];
 	const int tid = threadIdx.x;
-#if OP_PYR_EXPERIMENT == 9
-	unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-	const unsigned long long tbegin = tlast;
-#endif
 	// work item; consecutive items (neighbouring bands share cache lines at their seams, neighbouring
 	// segments their halo rows) are handed to one XCD, i.e. one L2
 	const unsigned lin = blockIdx.x, per = gridDim.x >> 3;
@@ -620,10 +598,6 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 	const unsigned allow = (sc0 ? 0x0Fu : 0u) | (sc1 ? 0xF0u : 0u);
 	unsigned pm = 0;                                              // rr == 1: the gate mask of the row produced in the previous pair
 	if (tid < 2) sQn[tid] = 0;
-#if OP_PYR_EXPERIMENT == 9
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the window has landed: the prologue ends here
-#endif
-	PSTAMP(7);
 
 	for (int t = 0; t < nsteps; ++t) {
 		const int r = y0 - 1 + 2 * t;
@@ -634,7 +608,7 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 			f32x2 a0[3], a1[3];
 #define OP_WMUL(i, kp) ((((i) & 1) ? __builtin_shufflevector(win[(i) >> 1], win[(i) >> 1], 1, 1) : __builtin_shufflevector(win[(i) >> 1], win[(i) >> 1], 0, 0)) * (kp))
 #pragma unroll
-			for (int k = 0; k < (OP_PYR_EXPERIMENT == 5 ? 1 : 13); ++k) {
+			for (int k = 0; k < 13; ++k) {
 				const int d = k < 6 ? 6 - k : k - 6;
 				if (k == 0) { a0[1] = OP_WMUL(k, KP1[d]); a1[1] = OP_WMUL(k + 1, KP1[d]); a0[2] = OP_WMUL(k, KP2[d]); a1[2] = OP_WMUL(k + 1, KP2[d]); }
 				else {
@@ -647,18 +621,12 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 					a0[0] = a0[0] + OP_WMUL(k, KP0[d0]); a1[0] = a1[0] + OP_WMUL(k + 1, KP0[d0]);
 				}
 			}
-			if (OP_PYR_EXPERIMENT == 5) { a0[0] = a0[1]; a1[0] = a1[1]; }
 #undef OP_WMUL
-#if OP_PYR_EXPERIMENT == 9
-			asm volatile("s_nop 0" :: "v"(a0[0]), "v"(a1[0]), "v"(a0[1]), "v"(a1[1]), "v"(a0[2]), "v"(a1[2]));
-#endif
-			PSTAMP(0);
 #pragma unroll
 			for (int pl = 0; pl < 3; ++pl) { sV[pl][0][tid] = a0[pl]; sV[pl][1][tid] = a1[pl]; }
 			sGrey[0][tid] = win[3].x; sGrey[1][tid] = win[3].y;
 		}
 		lds_barrier();
-		PSTAMP(1);
 
 		// ---- row pass + DoG for (row r + rr; columns h, h+1)
 		float dcur[2][6];
@@ -671,7 +639,7 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				for (int i = 0; i < 10; ++i) w[i] = sV[0][rr][h + 2 + i];
 				f32x2 a = w[1] * KP0[3], b = w[2] * KP0[3];
 #pragma unroll
-				for (int k = 1; k < (OP_PYR_EXPERIMENT == 4 ? 1 : 7); ++k) {
+				for (int k = 1; k < 7; ++k) {
 					const int d = k < 3 ? 3 - k : k - 3;
 					a = a + w[k + 1] * KP0[d]; b = b + w[k + 2] * KP0[d];
 				}
@@ -684,7 +652,7 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				for (int i = 0; i < 14; ++i) w[i] = sV[pl][rr][h + i];
 				f32x2 a = w[0] * (pl == 1 ? KP1[6] : KP2[6]), b = w[1] * (pl == 1 ? KP1[6] : KP2[6]);
 #pragma unroll
-				for (int k = 1; k < (OP_PYR_EXPERIMENT == 4 ? 1 : 13); ++k) {
+				for (int k = 1; k < 13; ++k) {
 					const int d = k < 6 ? 6 - k : k - 6;
 					const f32x2 kp = pl == 1 ? KP1[d] : KP2[d];
 					a = a + w[k] * kp; b = b + w[k + 1] * kp;
@@ -706,13 +674,9 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				dcur[0][l] = D[l].x; dcur[1][l] = D[l].y;
 			}
 			const int slot = (2 * t + rr) & (OP_RING_ROWS - 1);
-#if OP_PYR_EXPERIMENT == 9
-			asm volatile("s_nop 0" :: "v"(dcur[0][0]), "v"(dcur[1][5]), "v"(dcur[0][3]), "v"(dcur[1][2]));
-#endif
-			PSTAMP(2);
 #pragma unroll
 			for (int l = 0; l < 6; ++l) *(f32x2*)&sD[slot][l][h] = D[l];
-			if (OP_PYR_EXPERIMENT != 3 && st0 && y >= y0 && y < y0 + rows_own) {
+			if (st0 && y >= y0 && y < y0 + rows_own) {
 				const unsigned bo = ((unsigned)y * (unsigned)od.w + (unsigned)x) * 4u;
 				if (st1) {
 #pragma unroll
@@ -729,7 +693,6 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				for (int l = 0; l < 6; ++l) dcur[e][l] = 0.f;
 		}
 
-		PSTAMP(3);
 		// ---- gate: rr == 0 scans its current row r (row r+1 is written by the other half in this
 		// pair), rr == 1 scans the row it produced in the previous pair (r-1)
 		// Every thread gates the 8 candidates of ITS row (2 columns x DoG layers 1..4, extrema.cc:179) into a bit mask:
@@ -739,9 +702,6 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 		unsigned mine = 0;                                        // candidates that did not fit the queue
 		const int rru = __builtin_amdgcn_readfirstlane(rr);
 		const int ysc = rru == 0 ? r : r - 1;
-#if OP_PYR_EXPERIMENT == 1 || OP_PYR_EXPERIMENT == 2
-		if (false)
-#endif
 		{
 			unsigned cm = 0;
 #pragma unroll
@@ -770,17 +730,10 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				}
 			}
 		}
-		PSTAMP(4);
-#if OP_PYR_EXPERIMENT != 2
 		lds_barrier();
-#endif
-		PSTAMP(5);
 
 		// ---- scan the queue: one entry per thread
 		if (tid == 0) sQn[(t + 1) & 1] = 0;
-#if OP_PYR_EXPERIMENT == 1 || OP_PYR_EXPERIMENT == 2
-		if (false)
-#endif
 		{
 			int n = sQn[t & 1]; n = n > RW_QCAP ? RW_QCAP : n;
 			for (int i = tid; i < n; i += 256) {
@@ -805,24 +758,8 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 #pragma unroll
 		for (int i = 0; i < 6; ++i) win[i] = win[i + 1];
 		win[6] = nxt;
-		PSTAMP(6);
 	}
-#if OP_PYR_EXPERIMENT == 9
-	if (tid == 0) {
-		for (int k = 0; k < 8; ++k) atomicAdd(&g_pyr_timers[k], tacc[k]);
-		atomicAdd(&g_pyr_timers[8], clock64() - tbegin); atomicAdd(&g_pyr_timers[9], 1ULL); atomicAdd(&g_pyr_timers[10], (unsigned long long)nsteps);
-	}
-#endif
 }
-#if OP_PYR_EXPERIMENT == 9
-}	// namespace
-extern "C" int op_debug_pyr_timers(unsigned long long* out) {
-	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pyr_timers), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
-	unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	return hipMemcpyToSymbol(HIP_SYMBOL(g_pyr_timers), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-namespace {
-#endif
 
 // debug / staged dump: GaussianPyramid::cal_mag_ort (feature/dog.cc:60-94) of one Gaussian plane
 __global__ void __launch_bounds__(256) k_magort_plane(SiftPlan p, int img, int o, int s, float* mag, float* ort) {
@@ -875,12 +812,6 @@ hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float
 	return hipGetLastError();
 }
 
-// OPENPANO_PYRAMID=tiles selects the tiled kernel (K3) also for the shipped bank (tests, A/B timing)
-static bool pyramid_force_tiles() {
-	static const bool v = [] { const char* e = getenv("OPENPANO_PYRAMID"); return e && std::string(e) == "tiles"; }();
-	return v;
-}
-
 hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, hipStream_t st) {
 	size_t lds = pyramid_lds_bytes(p.halo);
 	{	// per-function attribute; idempotent, so concurrent first calls from several host threads are harmless
@@ -888,7 +819,7 @@ hipError_t launch_pyramid(const SiftPlan& p, int* raw, int* raw_count, int cap, 
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pyramid<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 		if (e != hipSuccess) return e;
 	}
-	if (p.rows_ok && !pyramid_force_tiles()) {
+	if (p.rows_ok) {           // the shipped Gaussian bank: row-streaming kernel; any other bank: tiles
 		const unsigned blocks = (unsigned)p.n * (unsigned)p.rw_items;
 		hipLaunchKernelGGL(k_pyramid_rows, dim3(blocks), dim3(256), 0, st, p, raw, raw_count, cap);
 		return hipGetLastError();

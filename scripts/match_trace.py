@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU probe: per-phase cycle split of the matcher sweep (variant library built with -DOP_MATCH_EXPERIMENT=9)."""
+"""GPU probe: per-phase cycle split of the matcher sweep (variant library: scripts/build_variant.sh match9 match.hip -DOP_MATCH_EXPERIMENT=9, which applies scripts/experiments/match_timing_experiments.patch)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
