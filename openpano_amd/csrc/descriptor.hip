@@ -16,7 +16,8 @@
 //       ORs its lane bit into the 64-bit LDS mask of each bin it touches (order-free atomics),
 //       a contribution's rank inside its bin is the popcount of that mask below the lane, bin
 //       offsets are a 128-entry scan of the mask popcounts; the values land bin-major in LDS,
-//       in sample order inside each bin;
+//       in sample order inside each bin;  (a workgroup is ONE wavefront: its LDS accesses execute
+//       in program order, and a barrier is a compiler fence plus a wait, not a rendezvous)
 //   3   lane L owns bins L and L+64 and adds their segments in order to its two fp32
 //       accumulators -- every bin sees exactly the reference's sequence of additions.
 // The window is not scanned whole: per window column only the rows that can pass the circle and
@@ -37,8 +38,8 @@ struct DescLds {
 	int q_gi[QCAP];                  // survivor queue (ring): plane offset, rotated coordinates
 	float q_xr[QCAP], q_yr[QCAP];
 	uint64_t exptab[32];             // glibc's exp2f table (devmath.hpp), staged once per workgroup
-	short col_lo[64], col_start[64]; // column c of the window: first candidate row, index of its first candidate
-	unsigned char colmap[COLCAP];    // candidate index -> window column
+	unsigned long long startbits[COLCAP / 64];   // bit e: candidate e is the first of its window column
+	unsigned colpk[64];              // k-th non-empty window column: index of its first candidate << 16 | (first candidate row & 0xFF) << 8 | column
 };
 
 // Wave64 inclusive add-scan and max-reduction on the VALU data-parallel primitives (row_shr within the
@@ -143,9 +144,17 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			ncand = __builtin_amdgcn_readlane(incl, 63);
 			cols = ncand <= COLCAP;
 			if (cols) {
+				// candidate -> (column, row) without a per-candidate table: one bit per column marks its first candidate,
+				// the columns that have candidates are listed compactly; candidate e of a 64-candidate step then belongs to
+				// the (columns started before the step + marks at or below e)-th listed column
 				const int start = incl - len;
-				S.col_lo[lane] = (short)lo; S.col_start[lane] = (short)start;
-				for (int k = 0; k < len; ++k) S.colmap[start + k] = (unsigned char)lane;
+				const unsigned long long nonempty = __ballot(len > 0);
+				if (lane < COLCAP / 64) S.startbits[lane] = 0ULL;
+				__syncthreads();
+				if (len > 0) {
+					atomicOr(&S.startbits[start >> 6], 1ULL << (start & 63));
+					S.colpk[rank_below(nonempty)] = ((unsigned)start << 16) | (((unsigned)lo & 0xFFu) << 8) | (unsigned)lane;
+				}
 			} else ncand = nsamp;
 			__syncthreads();
 		}
@@ -202,7 +211,8 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			{
 				const int base = (lane >> 2) * 8, k0 = 2 * (lane & 3);          // this lane computes the offsets of bins 2 lane, 2 lane + 1
 				const unsigned long long mp = S.mask[base + ((k0 + 7) & 7)], m0 = S.mask[base + k0], m1 = S.mask[base + k0 + 1];
-				const int c0 = __popcll(m0 | mp), c1 = __popcll(m1 | m0);
+				const unsigned long long u0 = m0 | mp, u1 = m1 | m0;       // contributors of bins 2 lane and 2 lane + 1
+				const int c0 = __popcll(u0), c1 = __popcll(u1);
 				const int p0 = (c0 + 3) & ~3, p1 = (c1 + 3) & ~3;         // list lengths rounded up to whole float4s
 				const int incl = wave_scan_add(p0 + p1);                   // inclusive wave scan of the per-lane pair sizes
 				const int ex = incl - (p0 + p1);
@@ -212,15 +222,18 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 				// (after the barrier) overwrites the slots that hold values.
 				if (p0) *(f32x4*)&S.sorted[ex + p0 - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
 				if (p1) *(f32x4*)&S.sorted[ex + p0 + p1 - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+				// from here on only the contributor sets are needed: they replace the raw masks in place (every lane's three
+				// reads above precede every lane's two writes below: one wavefront, LDS accesses in program order)
+				__syncthreads();
+				S.mask[base + k0] = u0; S.mask[base + k0 + 1] = u1;
 			}
 			__syncthreads();
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
 				if (cb[u] >= 0) {
 					const int hn = (hq + 1) & 7;
-					const unsigned long long mp = S.mask[cb[u] + ((hq + 7) & 7)], m0 = S.mask[cb[u] + hq], mn = S.mask[cb[u] + hn];
-					S.sorted[S.off[cb[u] + hq] + rank_below(m0 | mp)] = vA[u];
-					S.sorted[S.off[cb[u] + hn] + rank_below(mn | m0)] = vB[u];
+					S.sorted[S.off[cb[u] + hq] + rank_below(S.mask[cb[u] + hq])] = vA[u];
+					S.sorted[S.off[cb[u] + hn] + rank_below(S.mask[cb[u] + hn])] = vB[u];
 				}
 			__syncthreads();
 			// phase 3: ordered accumulation.  Lane L owns bins L and L + 64 (cells 8 apart: when one is
@@ -228,8 +241,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 			// float4 at a time (16-byte aligned, zero-padded), the four additions of a group stay in order;
 			// the trip count is wave-uniform, lanes whose list has ended skip the group.
 			{
-				const int bprev = (lane & ~7) | ((lane + 7) & 7);          // bin (cell, k - 1) of bin `lane` = (cell, k)
-				const int na = (__popcll(S.mask[lane] | S.mask[bprev]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64] | S.mask[bprev + 64]) + 3) & ~3;
+				const int na = (__popcll(S.mask[lane]) + 3) & ~3, nb = (__popcll(S.mask[lane + 64]) + 3) & ~3;
 				const f32x4* la = (const f32x4*)&S.sorted[S.off[lane]];
 				const f32x4* lb = (const f32x4*)&S.sorted[S.off[lane + 64]];
 				const int T = wave_max_i(na > nb ? na : nb);
@@ -253,15 +265,22 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 		// cheap tests run on all candidates, survivors are queued in order and handed to the expensive
 		// phases 64 at a time, so those always run with full wavefronts
 		int qx = lane / side, qy = lane % side;          // full-window walk: sample e = i0 + lane  ->  (e / side, e % side)
+		int kbase = -1;                                  // listed columns started before this step, minus one
 		for (int i0 = 0; i0 < ncand; i0 += 64) {
 			bool ok = false;
 			float x_rot = 0.f, y_rot = 0.f;
 			int gi = 0;
+			int ord = 0;
+			if (cols) {
+				const unsigned long long sb = S.startbits[i0 >> 6];
+				ord = kbase + rank_below(sb) + (int)((unsigned)(sb >> lane) & 1u);
+				kbase += __popcll(sb);
+			}
 			if (i0 + lane < ncand) {
 				int xx, yy;
 				if (cols) {
-					const int e = i0 + lane, c = S.colmap[e];
-					xx = c - radius; yy = (int)S.col_lo[c] + (e - (int)S.col_start[c]);
+					const unsigned pk = S.colpk[ord];
+					xx = (int)(pk & 0xFFu) - radius; yy = (int)(signed char)(pk >> 8) + (i0 + lane - (int)(pk >> 16));
 				} else { xx = qx - radius; yy = qy - radius; }
 				const int nowx = kp.x + xx, nowy = kp.y + yy;
 				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {

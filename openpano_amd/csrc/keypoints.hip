@@ -21,41 +21,79 @@ struct DogView {
 
 // Eigen::FullPivLU 3x3 inverse as used by Matrix::inverse (lib/matrix.cc:76-87): complete
 // pivoting, rank threshold |pivot| > |maxpivot| * eps * 3, inverse = solve(Identity).
-__device__ bool inverse3_fullpiv(const double a[9], double inv[9]) {
+// Written without a single run-time array index: every loop is unrolled and a data-dependent
+// transposition is a chain of conditional swaps against the constant candidates, so the nine
+// entries, the right-hand side and the two permutation records stay in registers (indexed through
+// run-time pivots they went to scratch memory, a memory round trip per swapped element on the
+// critical path of a kernel that has two waves per SIMD to hide it with).
+__device__ __forceinline__ void cswap(bool c, double& a, double& b) { const double t = a; a = c ? b : a; b = c ? t : b; }
+__device__ __forceinline__ bool inverse3_fullpiv(const double a[9], double inv[9]) {
 	double lu[9];
 #pragma unroll
 	for (int i = 0; i < 9; ++i) lu[i] = a[i];
-	int rowt[3], colt[3], nonzero = 3;
+	int rowt[3] = {0, 1, 2}, colt[3] = {0, 1, 2}, nonzero = 3;
 	double maxpivot = 0;
+	bool live = true;                     // false once a zero pivot block ended the elimination (the reference's break)
+#pragma unroll
 	for (int k = 0; k < 3; ++k) {
 		int br = k, bc = k; double best = -1;
-		for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j) {
-			double v = fabs(lu[i * 3 + j]);
-			if (v > best) { best = v; br = i; bc = j; }
+#pragma unroll
+		for (int i = k; i < 3; ++i)
+#pragma unroll
+			for (int j = k; j < 3; ++j) {
+				const double v = fabs(lu[i * 3 + j]);
+				if (v > best) { best = v; br = i; bc = j; }
+			}
+		if (live && best == 0.0) { nonzero = k; live = false; }       // rowt / colt of the remaining steps stay the identity
+		if (live) {
+			if (best > maxpivot) maxpivot = best;
+			rowt[k] = br; colt[k] = bc;
+#pragma unroll
+			for (int r = k + 1; r < 3; ++r)
+#pragma unroll
+				for (int j = 0; j < 3; ++j) cswap(br == r, lu[k * 3 + j], lu[r * 3 + j]);
+#pragma unroll
+			for (int c = k + 1; c < 3; ++c)
+#pragma unroll
+				for (int i = 0; i < 3; ++i) cswap(bc == c, lu[i * 3 + k], lu[i * 3 + c]);
+#pragma unroll
+			for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
+#pragma unroll
+			for (int i = k + 1; i < 3; ++i)
+#pragma unroll
+				for (int j = k + 1; j < 3; ++j)
+					lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
 		}
-		if (best == 0.0) { nonzero = k; for (int i = k; i < 3; ++i) rowt[i] = colt[i] = i; break; }
-		if (best > maxpivot) maxpivot = best;
-		rowt[k] = br; colt[k] = bc;
-		if (br != k) for (int j = 0; j < 3; ++j) { double t = lu[k * 3 + j]; lu[k * 3 + j] = lu[br * 3 + j]; lu[br * 3 + j] = t; }
-		if (bc != k) for (int i = 0; i < 3; ++i) { double t = lu[i * 3 + k]; lu[i * 3 + k] = lu[i * 3 + bc]; lu[i * 3 + bc] = t; }
-		for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
-		for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j)
-			lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
 	}
 	const double thr = fabs(maxpivot) * (2.220446049250313e-16 * 3);
 	int rank = 0;
-	for (int i = 0; i < nonzero; ++i) rank += (fabs(lu[i * 3 + i]) > thr);
+#pragma unroll
+	for (int i = 0; i < 3; ++i) rank += (i < nonzero && fabs(lu[i * 3 + i]) > thr);
 	if (rank != 3) return false;
+#pragma unroll
 	for (int col = 0; col < 3; ++col) {
 		double c[3];
+#pragma unroll
 		for (int i = 0; i < 3; ++i) c[i] = (i == col) ? 1.0 : 0.0;
-		for (int i = 0; i < 3; ++i) { double t = c[i]; c[i] = c[rowt[i]]; c[rowt[i]] = t; }
-		for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
+#pragma unroll
+		for (int i = 0; i < 3; ++i)                                      // c[i] <-> c[rowt[i]], rowt[i] >= i
+#pragma unroll
+			for (int r = i + 1; r < 3; ++r) cswap(rowt[i] == r, c[i], c[r]);
+#pragma unroll
+		for (int i = 0; i < 3; ++i)
+#pragma unroll
+			for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
+#pragma unroll
 		for (int i = 2; i >= 0; --i) {
+#pragma unroll
 			for (int j = i + 1; j < 3; ++j) c[i] -= lu[i * 3 + j] * c[j];
 			c[i] /= lu[i * 3 + i];
 		}
-		for (int i = 2; i >= 0; --i) { double t = c[i]; c[i] = c[colt[i]]; c[colt[i]] = t; }
+#pragma unroll
+		for (int i = 2; i >= 0; --i)                                     // c[i] <-> c[colt[i]], colt[i] >= i
+#pragma unroll
+			for (int r = i + 1; r < 3; ++r) cswap(colt[i] == r, c[i], c[r]);
+#pragma unroll
 		for (int i = 0; i < 3; ++i) inv[i * 3 + col] = c[i];
 	}
 	return true;
@@ -346,20 +384,60 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 			if (lane < ORI_BINS) s_mask[lane] = 0ULL;
 			__syncthreads();
 		}
-		if (lane < ORI_BINS) s_hist[lane] = h;
-		__syncthreads();
-		if (lane == 0) {   // in-place sequential smoothing (:70-75)
-			for (int K = p.ori_smooth; K--;)
-				for (int i = 0; i < ORI_BINS; ++i) {
-					const float prev = s_hist[i == 0 ? ORI_BINS - 1 : i - 1];
-					const float next = s_hist[i == ORI_BINS - 1 ? 0 : i + 1];
-					s_hist[i] = (float)((double)s_hist[i] * 0.5 + (double)(prev + next) * 0.25);
+		// ---- in-place sequential smoothing (orientation.cc:70-75):  hist[i] = hist[i] * 0.5 + (hist[i-1] + hist[i+1]) * 0.25
+		// in double, bins in order, each step reading the ALREADY smoothed left neighbour: a recurrence of 36 dependent
+		// steps per pass.  Walked by one lane through LDS it was more than half of this kernel's instructions (10 VALU +
+		// an LDS round trip per bin).  Here the histogram stays in registers, bin b in lane b, and all lanes run the
+		// recurrence in lockstep: at step t every lane recomputes its bin from the left neighbour's latest value
+		// (DPP wave_shr:1), so after step t bins 0..t are final and stay unchanged.  The double arithmetic of one step is
+		// one fp32 fma:  (double)h * 0.5 and (double)s * 0.25 are exact, and a sum of two fp32-precision terms rounds to
+		// fp32 the same way directly as through a 53-bit intermediate (terms less than 2^29 apart add exactly in double;
+		// further apart, the small one cannot move the large one to or across an fp32 rounding boundary either way), so
+		// float(h * 0.5 + s * 0.25) = fma(s, 0.25f, h * 0.5f) whenever h * 0.5f is exact -- guaranteed by the guard
+		// below (no bin in the denormal neighbourhood); histograms that fail it take the lane-0 walk in double.
+		float hv = lane < ORI_BINS ? h : 0.f;
+		if (__ballot(hv != 0.f && hv < 0x1p-100f) == 0ULL) {
+			for (int K = p.ori_smooth; K--;) {
+				const float half = hv * 0.5f;
+				float nxt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hv), 0x130, 0xF, 0xF, false));   // wave_shl:1: old hist[b + 1]
+				int pv = __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), ORI_BINS - 1);      // lane 0 keeps the old hist[35] (no source lane for it below)
+				float cur = hv;
+#pragma unroll
+				for (int t = 0; t < ORI_BINS; ++t) {
+					pv = __builtin_amdgcn_update_dpp(pv, __builtin_bit_cast(int, cur), 0x138, 0xF, 0xF, false);     // wave_shr:1: the left neighbour's latest value
+					cur = __builtin_fmaf(__builtin_bit_cast(float, pv) + nxt, 0.25f, half);
+					if (t == 0) {       // bin 35's right neighbour is the NEW hist[0], final after this step
+						const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), 0));
+						nxt = lane == ORI_BINS - 1 ? n0 : nxt;
+					}
 				}
+				hv = lane < ORI_BINS ? cur : 0.f;
+			}
+			if (lane < ORI_BINS) s_hist[lane] = hv;
+			__syncthreads();
+		} else {
+			if (lane < ORI_BINS) s_hist[lane] = h;
+			__syncthreads();
+			if (lane == 0) {
+				for (int K = p.ori_smooth; K--;)
+					for (int i = 0; i < ORI_BINS; ++i) {
+						const float prev = s_hist[i == 0 ? ORI_BINS - 1 : i - 1];
+						const float next = s_hist[i == ORI_BINS - 1 ? 0 : i + 1];
+						s_hist[i] = (float)((double)s_hist[i] * 0.5 + (double)(prev + next) * 0.25);
+					}
+			}
+			__syncthreads();
+			hv = lane < ORI_BINS ? s_hist[lane] : 0.f;
 		}
-		__syncthreads();
-		const float hv = lane < ORI_BINS ? s_hist[lane] : 0.f;
-		float maxbin = 0.f;
-		for (int i = 0; i < ORI_BINS; ++i) maxbin = maxbin < s_hist[i] ? s_hist[i] : maxbin;
+		// the largest bin (orientation.cc:78-80: a running maximum from 0 that a NaN never replaces = v_max_f32 across the wave)
+		float maxbin = hv;
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x111, 0xF, 0xF, false)));
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x112, 0xF, 0xF, false)));
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x114, 0xF, 0xF, false)));
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x118, 0xF, 0xF, false)));
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x142, 0xA, 0xF, false)));
+		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x143, 0xC, 0xF, false)));
+		maxbin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, maxbin), 63));
 		const float thres = maxbin * 0.8f;                              // ORI_HIST_PEAK_RATIO
 		bool peak = false; float ort = 0.f;
 		if (lane < ORI_BINS) {
