@@ -71,7 +71,7 @@ __device__ __forceinline__ int rank_below(unsigned long long m) {
 }
 
 __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* oriented,
-		const long long* img_offset, long long cap, float* desc, double* coor, double* real) {
+		const long long* total_ptr, long long cap, float* desc, double* coor, double* real) {
 	__shared__ DescLds S;
 	const int lane = threadIdx.x;
 	const float pi2 = (float)(2 * 3.14159265358979323846);
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 	if (lane < 32) S.exptab[lane] = opdev::kExp2fTab[lane];
 	__syncthreads();
 
-	long long total = img_offset[p.n];                 // device-side count (k_image_offsets)
+	long long total = *total_ptr;                      // device-side count (k_expand_oriented)
 	total = total < cap ? total : cap;                 // speculative capacity: the host re-runs on overflow
 	for (long long kk = blockIdx.x; kk < total; kk += gridDim.x) {
 		const KeyPoint kp = oriented[kk];
@@ -333,10 +333,10 @@ __global__ void __launch_bounds__(64) k_descriptor(SiftPlan p, const KeyPoint* o
 
 }	// namespace
 
-hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset,
+hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* total,
 		long long cap, float* desc, double* coor, double* real, hipStream_t st) {
 	if (cap <= 0) return hipSuccess;
 	const int grid = (int)(cap < (1 << 20) ? cap : (1 << 20));  // one keypoint per wavefront; wavefronts beyond the device-side count exit at once
-	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, img_offset, cap, desc, coor, real);
+	hipLaunchKernelGGL(k_descriptor, dim3(grid), dim3(64), 0, st, p, oriented, total, cap, desc, coor, real);
 	return hipGetLastError();
 }

@@ -125,6 +125,8 @@ struct SiftPlan {
 	float* work;                // n x wh x ww x 3 (only materialised for the staged dump)
 	const void* const* srcs;    // device array of n source pointers (device memory)
 	int src_u8;                 // 0: fp32 sources, 1: uint8 sources (converted like read_img, lib/imgio.cc:54-56)
+	int* zero;                  // batch counters cleared by the first kernel of the step (k_grey_octaves), zero_n ints
+	int zero_n;
 	// Gaussian bank (feature/gaussian.cc:17-40): kern[s][center + k], s = 1..nscale-1
 	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
 	int kcenter[OP_MAX_SCALE];
@@ -176,16 +178,16 @@ hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count
 		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
 hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
 		KeyPoint* out, hipStream_t st);
+// per_image[img * OP_OCNT_STRIDE] += orientation peaks of every keypoint (atomic; one counter per 128-byte line; cleared at the start of the step)
+#define OP_OCNT_STRIDE 32
 hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		float* dirs /* n x cap x 36 */, int* ndirs /* n x cap */, hipStream_t st);
+		float* dirs /* n x cap x 36 */, int* ndirs /* n x cap */, int* per_image /* n x OP_OCNT_STRIDE */, hipStream_t st);
+// image img's keypoints land at [sum of the earlier images' counts, ...); *total = sum of all, count_out[0..n) = the counts packed
+// (device-side, no host round trip)
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		const float* dirs, const int* ndirs, const long long* img_offset /* n+1, device */,
+		const float* dirs, const int* ndirs, const int* per_image /* n x OP_OCNT_STRIDE */, long long* total, int* count_out /* n */,
 		KeyPoint* oriented, long long oriented_cap, hipStream_t st);
-// device-side exclusive prefix of the per-image counts: img_offset[0..n], img_offset[n] = total
-hipError_t launch_image_offsets(const SiftPlan& p, const int* per_image, long long* img_offset, hipStream_t st);
-hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
-		int* per_image /* n */, hipStream_t st);
-// the descriptor count is read on the device (img_offset[n]); cap = capacity of the output buffers
-hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* img_offset /* n+1 device */,
+// the descriptor count is read on the device (*total); cap = capacity of the output buffers
+hipError_t launch_descriptor(const SiftPlan& p, const KeyPoint* oriented, const long long* total /* device */,
 		long long cap, float* desc, double* coor, double* real, hipStream_t st);
 hipError_t launch_debug_math(int which, const float* x, const float* y, int n, float* out, hipStream_t st);

@@ -281,6 +281,10 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 // Samples are evaluated 64 at a time, but each histogram bin is accumulated by ONE lane walking
 // the samples in the reference's (xx outer, yy inner) order, so the fp32 sums round identically.
 constexpr int ORI_BINS = 36;
+// The per-image descriptor counters that k_orientation's wavefronts add to lie one per 128-byte line: a thousand
+// atomics per image are nothing, but 38 adjacent counters are ONE line on ONE L2 channel, and 38 000 atomics in a row
+// on it took twice as long as the whole kernel.
+constexpr int OCNT_STRIDE = OP_OCNT_STRIDE;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // wave64 inclusive add-scan / max on the VALU data-parallel primitives (see descriptor.hip)
@@ -305,7 +309,7 @@ __device__ __forceinline__ int ori_max(int v) {
 }
 
 __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* refined, const int* refined_count,
-		int cap, float* dirs, int* ndirs) {
+		int cap, float* dirs, int* ndirs, int* per_image) {
 	__shared__ unsigned long long s_mask[ORI_BINS];   // per bin: bit l = lane l's sample of this round falls into it
 	__shared__ __attribute__((aligned(16))) float s_sorted[64 + 3 * ORI_BINS + 12];   // the round's values, bin-major, sample order inside a bin; lists 16-byte aligned, zero-padded to float4s
 	__shared__ unsigned short s_off[64];
@@ -317,6 +321,7 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 	const float halfipi = (float)(0.5f / 3.14159265358979323846);
 	if (lane < ORI_BINS) s_mask[lane] = 0ULL;
 	__syncthreads();
+	int npeaks = 0;                                   // lane 0: orientation peaks of this wavefront's keypoints
 	for (int k = blockIdx.x; k < count; k += gridDim.x) {
 		const KeyPoint kp = refined[(long long)img * cap + k];
 		const OctDesc od = p.oct[kp.oct];
@@ -456,76 +461,69 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 		const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
 		float* out = dirs + ((long long)img * cap + k) * ORI_BINS;
 		if (peak) out[pos] = ort;
-		if (lane == 0) ndirs[(long long)img * cap + k] = __popcll(mask);
+		if (lane == 0) {
+			const int np = __popcll(mask);
+			ndirs[(long long)img * cap + k] = np;
+			npeaks += np;
+		}
 		__syncthreads();
 	}
+	if (lane == 0 && npeaks) atomicAdd(&per_image[img * OCNT_STRIDE], npeaks);   // the image's descriptor count (order-free), one atomic per wavefront
 }
 
-// per-image total of orientation peaks (one workgroup per image)
-__global__ void __launch_bounds__(256) k_count_oriented(const int* refined_count, int cap, const int* ndirs, int* per_image) {
-	__shared__ int s_sum[256];
-	const int img = blockIdx.x;
-	const int n = refined_count[img];
-	int acc = 0;
-	for (int i = threadIdx.x; i < n; i += 256) acc += ndirs[(long long)img * cap + i];
-	s_sum[threadIdx.x] = acc;
-	__syncthreads();
-	for (int st = 128; st > 0; st >>= 1) {
-		if (threadIdx.x < st) s_sum[threadIdx.x] += s_sum[threadIdx.x + st];
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) per_image[img] = s_sum[0];
+// expansion refined -> oriented in (refined order, peak order): OrientationAssign::work (:22-32).  One workgroup per
+// image; its first output slot is the sum of the earlier images' counts (a few dozen ints, summed by every workgroup for
+// itself: no offsets kernel), workgroup 0 also leaves the batch total for the descriptor kernel and the host.
+__device__ __forceinline__ int exp_scan_add(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+	return v;
 }
-
-// exclusive prefix of the per-image descriptor counts -> img_offset[0..n] (img_offset[n] = total);
-// one workgroup, images in index order.  Keeps the host out of the middle of the pipeline.
-__global__ void __launch_bounds__(256) k_image_offsets(const int* __restrict__ per_image, int n, long long* __restrict__ img_offset) {
-	__shared__ long long s_part[256];
-	// each thread sums a contiguous chunk, then a serial pass over the 256 partials (n is tiny)
-	const int chunk = (n + 255) / 256;
-	const int b = threadIdx.x * chunk, e = b + chunk < n ? b + chunk : n;
-	long long acc = 0;
-	for (int i = b; i < e; ++i) acc += per_image[i];
-	s_part[threadIdx.x] = acc;
-	__syncthreads();
-	if (threadIdx.x == 0) { long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = s_part[t]; s_part[t] = run; run += v; } img_offset[n] = run; }
-	__syncthreads();
-	long long run = s_part[threadIdx.x];
-	for (int i = b; i < e; ++i) { img_offset[i] = run; run += per_image[i]; }
-}
-
-// expansion refined -> oriented in (refined order, peak order): OrientationAssign::work (:22-32)
 __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
-		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, long long oriented_cap) {
-	__shared__ int s_scan[256];
-	__shared__ int s_base;
-	const int img = blockIdx.x;
+		const float* dirs, const int* ndirs, const int* per_image, int nimg, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap) {
+	__shared__ long long s_before[256], s_all[256];
+	__shared__ int s_wave[4];
+	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int n = refined_count[img];
-	if (threadIdx.x == 0) s_base = 0;
-	__syncthreads();
-	for (int start = 0; start < n; start += 256) {
-		const int i = start + threadIdx.x;
-		const int cnt = i < n ? ndirs[(long long)img * cap + i] : 0;
-		s_scan[threadIdx.x] = cnt;
+	{
+		long long before = 0, all = 0;
+		for (int i = tid; i < nimg; i += 256) {
+			const int v = per_image[i * OCNT_STRIDE]; all += v; if (i < img) before += v;
+			if (img == 0) count_out[i] = v;                 // the counts, packed, next to the other counters the host reads
+		}
+		s_before[tid] = before; s_all[tid] = all;
 		__syncthreads();
-		for (int d = 1; d < 256; d <<= 1) {          // inclusive Hillis-Steele scan
-			int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
-			__syncthreads();
-			s_scan[threadIdx.x] += v;
+		for (int st = 128; st > 0; st >>= 1) {
+			if (tid < st) { s_before[tid] += s_before[tid + st]; s_all[tid] += s_all[tid + st]; }
 			__syncthreads();
 		}
-		const int excl = s_scan[threadIdx.x] - cnt + s_base;
+	}
+	long long base = s_before[0];
+	if (img == 0 && tid == 0) *total = s_all[0];
+	for (int start = 0; start < n; start += 256) {
+		const int i = start + tid;
+		const int cnt = i < n ? ndirs[(long long)img * cap + i] : 0;
+		const int incl = exp_scan_add(cnt);
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		int wbase = 0, chunk = 0;
+#pragma unroll
+		for (int w = 0; w < 4; ++w) { const int v = s_wave[w]; wbase += w < wave ? v : 0; chunk += v; }
+		const long long first = base + wbase + (incl - cnt);
 		if (i < n) {
 			KeyPoint kp = refined[(long long)img * cap + i];
 			const float* d = dirs + ((long long)img * cap + i) * ORI_BINS;
 			for (int j = 0; j < cnt; ++j) {
 				kp.dir = d[j]; kp.src = i; kp.pad = img;      // pad carries the image index to the descriptor kernel
-				const long long slot = img_offset[img] + excl + j;
+				const long long slot = first + j;
 				if (slot < oriented_cap) oriented[slot] = kp;       // speculative capacity: the host re-runs on overflow
 			}
 		}
-		__syncthreads();
-		if (threadIdx.x == 255) s_base += s_scan[255];
+		base += chunk;
 		__syncthreads();
 	}
 }
@@ -547,26 +545,15 @@ hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int*
 }
 
 hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		float* dirs, int* ndirs, hipStream_t st) {
+		float* dirs, int* ndirs, int* per_image, hipStream_t st) {
 	// grid-stride over the (device-side) keypoint count: no host round trip for the count
 	dim3 grid(cap < 1024 ? cap : 1024, p.n);
-	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs, ndirs);
-	return hipGetLastError();
-}
-
-hipError_t launch_count_oriented(const SiftPlan& p, const int* refined_count, int cap, const int* ndirs,
-		int* per_image, hipStream_t st) {
-	hipLaunchKernelGGL(k_count_oriented, dim3(p.n), dim3(256), 0, st, refined_count, cap, ndirs, per_image);
+	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs, ndirs, per_image);
 	return hipGetLastError();
 }
 
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		const float* dirs, const int* ndirs, const long long* img_offset, KeyPoint* oriented, long long oriented_cap, hipStream_t st) {
-	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, img_offset, oriented, oriented_cap);
-	return hipGetLastError();
-}
-
-hipError_t launch_image_offsets(const SiftPlan& p, const int* per_image, long long* img_offset, hipStream_t st) {
-	hipLaunchKernelGGL(k_image_offsets, dim3(1), dim3(256), 0, st, per_image, p.n, img_offset);
+		const float* dirs, const int* ndirs, const int* per_image, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap, hipStream_t st) {
+	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, per_image, p.n, total, count_out, oriented, oriented_cap);
 	return hipGetLastError();
 }

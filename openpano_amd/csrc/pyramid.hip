@@ -70,6 +70,10 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 	const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WR;
 	const int tid = threadIdx.x;
 	const SrcT* src = (const SrcT*)p.srcs[img];
+	// the step's counters (raw / refined / oriented per image, total) start at zero: cleared here, by the first kernel
+	// of the step, instead of by a fill launch of their own (nothing reads or adds to them before this kernel has ended)
+	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.zero)
+		for (int i = tid; i < p.zero_n; i += 256) p.zero[i] = 0;
 	if (sizeof(SrcT) == 1) s_lut[tid] = (float)((double)(float)tid / 255.0);      // (float)byte / 255.0: float -> double, IEEE division, round to float
 	// working-image tile: lib/imgproc.cc:22-80 on the source
 	{

@@ -34,14 +34,16 @@ struct DevBuf {
 }	// namespace
 
 struct Workspace {
-	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, offsets, oriented;
-	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch for counts/offsets
+	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, oriented;
+	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch: source pointer table, counter block
+	std::vector<const void*> srcs_last; void* srcs_dev = nullptr;   // the pointer table the device holds (and where)
 	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
 	int raw_cap = 16384;                             // per-image capacity of the raw / refined lists; grows on overflow (run_group)
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
-		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); offsets.release(); oriented.release();
+		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); oriented.release();
 		if (pinned) hipHostFree(pinned); pinned = nullptr; pinned_cap = 0;
+		srcs_last.clear(); srcs_dev = nullptr;
 	}
 };
 
@@ -232,12 +234,13 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	if (keep) HIPCHK(W.work.ensure(sizeof(float) * (size_t)plan.wh * plan.ww * 3 * n));
 	HIPCHK(W.srcs.ensure(sizeof(float*) * n));
 	HIPCHK(W.raw.ensure(sizeof(int) * 4 * (size_t)cap * n));
-	HIPCHK(W.counts.ensure(sizeof(int) * 4 * n));            // raw | refined | oriented | spare
+	// batch total (64 bits) | raw | refined | oriented (the block the host reads) | padding to a line | k_orientation's counters, one per line
+	const size_t cnt_hdr = ((3 * (size_t)n + 2) + 31) & ~(size_t)31;
+	HIPCHK(W.counts.ensure(sizeof(int) * (cnt_hdr + (size_t)n * OP_OCNT_STRIDE)));
 	HIPCHK(W.refinedA.ensure(sizeof(KeyPoint) * (size_t)cap * n));
 	HIPCHK(W.refinedB.ensure(sizeof(KeyPoint) * (size_t)cap * n));
 	HIPCHK(W.dirs.ensure(sizeof(float) * 36 * (size_t)cap * n));
 	HIPCHK(W.ndirs.ensure(sizeof(int) * (size_t)cap * n));
-	HIPCHK(W.offsets.ensure(sizeof(long long) * (n + 1)));
 	const size_t pin_need = sizeof(long long) * (size_t)(8 * n + 16);
 	if (W.pinned_cap < pin_need) {
 		if (W.pinned) hipHostFree(W.pinned);
@@ -278,14 +281,21 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 				}
 			}
 		}
-		HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+		// the pointer table only travels when it differs from the one the device already holds (a caller that keeps
+		// its images resident passes the same pointers batch after batch)
+		if (W.srcs_dev != W.srcs.p || W.srcs_last.size() != (size_t)n || !std::equal(W.srcs_last.begin(), W.srcs_last.end(), hs)) {
+			HIPCHK(hipMemcpyAsync(W.srcs.p, hs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+			W.srcs_last.assign(hs, hs + n); W.srcs_dev = W.srcs.p;
+		}
 	}
 	plan.srcs = (const void* const*)W.srcs.p;
 
-	int* d_raw_count = (int*)W.counts.p;
+	long long* d_total = (long long*)W.counts.p;
+	int* d_raw_count = (int*)W.counts.p + 2;
 	int* d_refined_count = d_raw_count + n;
 	int* d_oriented_count = d_raw_count + 2 * n;
-	HIPCHK(hipMemsetAsync(W.counts.p, 0, sizeof(int) * 4 * n, st));
+	int* d_ocnt = (int*)W.counts.p + cnt_hdr;
+	plan.zero = (int*)W.counts.p; plan.zero_n = (int)(cnt_hdr + (size_t)n * OP_OCNT_STRIDE);      // cleared by k_grey_octaves
 
 	{ ProfScope ps(ctx, "resize + octave grey"); HIPCHK(launch_grey_octaves(plan, keep != nullptr, st)); }
 	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
@@ -293,18 +303,16 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
 	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st)); }
 	{ ProfScope ps(ctx, "orientation");
-	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, st));
-	  HIPCHK(launch_count_oriented(plan, d_refined_count, cap, (const int*)W.ndirs.p, d_oriented_count, st)); }
+	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt, st)); }
 
 	// The descriptor count is only known on the device at this point.  Instead of a round trip,
 	// the output buffers get a capacity predicted from the previous call of this context (x1.25,
-	// at least 2048 per image), offsets are computed on the device and the remaining stages are
+	// at least 2048 per image), output offsets and the total are computed on the device and the remaining stages are
 	// enqueued right away; ONE synchronisation at the end returns the counts, and a batch that
 	// outgrew the prediction re-runs its last two stages with exact sizes.
-	HIPCHK(launch_image_offsets(plan, d_oriented_count, (long long*)W.offsets.p, st));
 	long long capK = std::max<long long>((long long)n * 2048, W.last_total + W.last_total / 4);
-	int* h_counts = (int*)((char*)W.pinned + 16 * (size_t)n);                  // pinned: [16n, 28n) counts
-	long long* h_total = (long long*)((char*)W.pinned + 32 * (size_t)n);     // pinned: [32n, ..) total
+	long long* h_total = (long long*)((char*)W.pinned + 16 * (size_t)n);     // pinned: [16n, ..) the counter block as it lies on the device
+	int* h_counts = (int*)h_total + 2;
 	long long total = 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		HIPCHK(W.oriented.ensure(sizeof(KeyPoint) * (size_t)capK));
@@ -313,11 +321,10 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 		HIPCHK(pool_alloc((void**)&res.real, sizeof(double) * 2 * (size_t)capK));
 		{ ProfScope ps(ctx, "orientation");
 		  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
-					(const int*)W.ndirs.p, (const long long*)W.offsets.p, (KeyPoint*)W.oriented.p, capK, st)); }
+					(const int*)W.ndirs.p, d_ocnt, d_total, d_oriented_count, (KeyPoint*)W.oriented.p, capK, st)); }
 		{ ProfScope ps(ctx, "sift descriptor");
-		  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, (const long long*)W.offsets.p, capK, res.desc, res.coor, res.real, st)); }
-		HIPCHK(hipMemcpyAsync(h_counts, W.counts.p, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
-		HIPCHK(hipMemcpyAsync(h_total, (const long long*)W.offsets.p + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+		  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, d_total, capK, res.desc, res.coor, res.real, st)); }
+		HIPCHK(hipMemcpyAsync(h_total, W.counts.p, sizeof(int) * (3 * (size_t)n + 2), hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		total = *h_total;
 		if (total <= capK) break;
