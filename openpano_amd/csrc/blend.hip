@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_mb_blur_fused(const BlendImg* __restric
 		const float4* __restrict__ src, float4* __restrict__ dst, float* __restrict__ target, unsigned char* __restrict__ tmask, int H, int W) {
 	constexpr int NT = 2 * CT + 1;          // taps
 	constexpr int TWO = 256 - 2 * CT;       // output columns of a band
-	constexpr int SEG = 4 * NT;             // rows of a segment (a whole number of window rotations)
+	constexpr int SEG = (CT <= 6 ? 8 : 6) * NT;   // rows of a segment (a whole number of window rotations; its 2 CT halo rows are re-read: 12 % / 16 %)
 	__shared__ float4 s_mid[2][256];
 	const BlendImg& im = imgs[blockIdx.y];
 	const int rw = im.rw, rh = im.rh;
@@ -343,6 +343,62 @@ __global__ void __launch_bounds__(256) k_mb_accumulate(const BlendImg* __restric
 		p0 = fmaxf(fminf(p0, 1.0f), 0.f); p1 = fmaxf(fminf(p1, 1.0f), 0.f); p2 = fmaxf(fminf(p2, 1.0f), 0.f);
 	}
 	p[0] = p0; p[1] = p1; p[2] = p2;
+}
+
+// ---- all remaining bands in ONE pass over the canvas.  The per-level form above reads, for every canvas pixel and every
+// image covering it, the level's plane AND the next one (which the next level's pass reads again as its own), and moves
+// the canvas through HBM once per level.  With every level's plane kept (they are a few hundred MB), a thread walks the
+// covering images once, reads each level's WeightedPixel once, keeps one (sum, weight) accumulator per level -- each
+// level's sum still runs over the images in index order -- and applies the bands to its canvas pixel in level order:
+// the same operations on the same operands in the same order as NL launches of k_mb_accumulate.
+#define OP_MB_MAX_LEVELS 6
+struct BandPlanes { const float4* lv[OP_MB_MAX_LEVELS]; };
+template <int NL>          // levels P.lv[0 .. NL-1]; the last one is the final level of the pyramid (no next plane; clamps)
+__global__ void __launch_bounds__(256) k_mb_bands(const BlendImg* __restrict__ imgs, int n, BandPlanes P,
+		const unsigned char* __restrict__ mask, float* __restrict__ out, unsigned char* __restrict__ tmask, int H, int W) {
+	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (i >= H || j >= W) return;
+	float s0[NL], s1[NL], s2[NL], ws[NL];
+#pragma unroll
+	for (int l = 0; l < NL; ++l) { s0[l] = 0.f; s1[l] = 0.f; s2[l] = 0.f; ws[l] = 0.f; }
+	for (int k = 0; k < n; ++k) {
+		const BlendImg& im = imgs[k];
+		if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) continue;
+		const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
+		if (mask[e]) continue;
+		float4 lvl[NL];
+#pragma unroll
+		for (int l = 0; l < NL; ++l) lvl[l] = P.lv[l][e];
+#pragma unroll
+		for (int l = 0; l < NL; ++l) {
+			const float4 cc = lvl[l];
+			if (cc.w <= 0) continue;
+			if (l < NL - 1) {
+				const float4 cn = lvl[l + 1];
+				s0[l] += (cc.x - cn.x) * cc.w; s1[l] += (cc.y - cn.y) * cc.w; s2[l] += (cc.z - cn.z) * cc.w;
+			} else {
+				s0[l] += cc.x * cc.w; s1[l] += cc.y * cc.w; s2[l] += cc.z * cc.w;
+			}
+			ws[l] += cc.w;
+		}
+	}
+	const long long pe = (long long)i * W + j;
+	float* p = out + pe * 3;
+	const bool seen0 = tmask[pe] != 0;
+	bool seen = seen0;
+	float p0 = p[0], p1 = p[1], p2 = p[2];
+#pragma unroll
+	for (int l = 0; l < NL; ++l) {
+		if (!((double)ws[l] < 1e-6)) {
+			const float a0 = s0[l] / ws[l], a1 = s1[l] / ws[l], a2 = s2[l] / ws[l];
+			if (!seen) { p0 = a0; p1 = a1; p2 = a2; seen = true; }
+			else { p0 += a0; p1 += a1; p2 += a2; }
+		}
+	}
+	if (seen) { p0 = fmaxf(fminf(p0, 1.0f), 0.f); p1 = fmaxf(fminf(p1, 1.0f), 0.f); p2 = fmaxf(fminf(p2, 1.0f), 0.f); }
+	p[0] = p0; p[1] = p1; p[2] = p2;
+	if (seen && !seen0) tmask[pe] = 1;
 }
 
 // ---- CylinderProject::project (stitch/warp.cc:25-44): thread per output pixel ----
@@ -681,19 +737,26 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		BCHK(hipGetLastError());
 	} else {
 		const int L = cfg->MULTIBAND;
-		float4 *cur = nullptr, *nxt = nullptr, *tmp = nullptr; unsigned char *mask = nullptr, *tmask = nullptr;
-		BCHK(pool_alloc((void**)&cur, sizeof(float4) * roi_total)); fr.v.push_back(cur);
-		BCHK(pool_alloc((void**)&nxt, sizeof(float4) * roi_total)); fr.v.push_back(nxt);
-		BCHK(pool_alloc((void**)&tmp, sizeof(float4) * roi_total)); fr.v.push_back(tmp);
+		// every level's plane is kept when they fit comfortably (L x 16 bytes per ROI pixel: 0.2 GB per level for 38 views):
+		// the bands are then applied in one pass over the canvas (k_mb_bands); otherwise two planes alternate and every
+		// level has its own band pass
+		const bool keep_all = L <= OP_MB_MAX_LEVELS && sizeof(float4) * (size_t)roi_total * (size_t)L <= ((size_t)64 << 30);
+		const int nplanes = keep_all ? L : 2;
+		std::vector<float4*> lv(nplanes, nullptr);
+		float4* tmp = nullptr; unsigned char *mask = nullptr, *tmask = nullptr;
+		for (int l = 0; l < nplanes; ++l) { BCHK(pool_alloc((void**)&lv[l], sizeof(float4) * roi_total)); fr.v.push_back(lv[l]); }
 		BCHK(pool_alloc((void**)&mask, roi_total)); fr.v.push_back(mask);
 		BCHK(pool_alloc((void**)&tmask, (size_t)H * W)); fr.v.push_back(tmask);
 		const dim3 rgrid((unsigned)((max_roi + 255) / 256), n);
 		{ ProfScope ps(ctx, "multiband first level");
-		  hipLaunchKernelGGL(k_mb_first_fused, dim3((W + 1 + 63) / 64, (H + 1 + 3) / 4), dim3(256), 0, st, bg, d_imgs, n, cur, mask, cv->data, tmask, H, W);
+		  hipLaunchKernelGGL(k_mb_first_fused, dim3((W + 1 + 63) / 64, (H + 1 + 3) / 4), dim3(256), 0, st, bg, d_imgs, n, lv[0], mask, cv->data, tmask, H, W);
 		  BCHK(hipGetLastError()); }
+		bool band0_done = false;                 // level 0's band written by the fused blur
 		for (int level = 0; level < L; ++level) {
 			const int is_last = (level == L - 1);
-			bool band_done = false;              // level 0's band written by the fused blur
+			float4* cur = keep_all ? lv[level] : lv[level & 1];
+			float4* nxt = is_last ? nullptr : (keep_all ? lv[level + 1] : lv[(level + 1) & 1]);
+			bool band_done = false;
 			if (!is_last) {
 				ProfScope ps(ctx, "multiband blur");
 				BlurTaps taps; memset(&taps, 0, sizeof(taps));
@@ -701,7 +764,7 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 					pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
 				}
 				if (taps.center == 6 || taps.center == 9) {       // shipped GAUSS_WINDOW_FACTOR: both passes in one kernel
-					const int C = taps.center, two = 256 - 2 * C, segr = 4 * (2 * C + 1);
+					const int C = taps.center, two = 256 - 2 * C, segr = (C <= 6 ? 8 : 6) * (2 * C + 1);
 					unsigned items = 1;
 					for (int k = 0; k < n; ++k)
 						items = std::max(items, (unsigned)(((h_imgs[k].rw + two - 1) / two) * ((h_imgs[k].rh + segr - 1) / segr)));
@@ -711,15 +774,29 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 					else if (level == 0) hipLaunchKernelGGL((k_mb_blur_fused<9, true>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
 					else hipLaunchKernelGGL((k_mb_blur_fused<9, false>), dim3(items, n), dim3(256), 0, st, d_imgs, taps, cur, nxt, cv->data, tmask, H, W);
 				} else {
+					if (!tmp) { BCHK(pool_alloc((void**)&tmp, sizeof(float4) * roi_total)); fr.v.push_back(tmp); }
 					hipLaunchKernelGGL((k_mb_blur<true, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, cur, tmp);
 					hipLaunchKernelGGL((k_mb_blur<false, 0>), rgrid, dim3(256), 0, st, d_imgs, taps, tmp, nxt);
 				}
 				BCHK(hipGetLastError());
 			}
-			if (!band_done) { ProfScope ps(ctx, "multiband band");
+			if (level == 0) band0_done = band_done;
+			if (!keep_all && !band_done) { ProfScope ps(ctx, "multiband band");
 			  hipLaunchKernelGGL(k_mb_accumulate, cgrid, dim3(256), 0, st, d_imgs, n, cur, nxt, mask, cv->data, tmask, H, W, is_last);
 			  BCHK(hipGetLastError()); }
-			std::swap(cur, nxt);
+		}
+		if (keep_all) {
+			ProfScope ps(ctx, "multiband band");
+			const int first = band0_done ? 1 : 0, NL = L - first;
+			BandPlanes P; memset(&P, 0, sizeof(P));
+			for (int l = 0; l < NL; ++l) P.lv[l] = lv[first + l];
+			switch (NL) {
+#define OP_MB_CASE(N) case N: hipLaunchKernelGGL((k_mb_bands<N>), cgrid, dim3(256), 0, st, d_imgs, n, P, mask, cv->data, tmask, H, W); break;
+				OP_MB_CASE(1) OP_MB_CASE(2) OP_MB_CASE(3) OP_MB_CASE(4) OP_MB_CASE(5) OP_MB_CASE(6)
+#undef OP_MB_CASE
+				default: break;
+			}
+			BCHK(hipGetLastError());
 		}
 	}
 	BCHK(hipStreamSynchronize(st));

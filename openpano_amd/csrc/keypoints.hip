@@ -483,28 +483,29 @@ __device__ __forceinline__ int exp_scan_add(int v) {
 	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
 	return v;
 }
-__global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
+constexpr int EXP_T = 1024;           // one pass over a thousand keypoints per image: every dependent round trip (counts -> keypoint + peaks -> store) once
+__global__ void __launch_bounds__(EXP_T) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const int* per_image, int nimg, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap) {
-	__shared__ long long s_before[256], s_all[256];
-	__shared__ int s_wave[4];
+	__shared__ long long s_before[EXP_T], s_all[EXP_T];
+	__shared__ int s_wave[EXP_T / 64];
 	const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int n = refined_count[img];
 	{
 		long long before = 0, all = 0;
-		for (int i = tid; i < nimg; i += 256) {
+		for (int i = tid; i < nimg; i += EXP_T) {
 			const int v = per_image[i * OCNT_STRIDE]; all += v; if (i < img) before += v;
 			if (img == 0) count_out[i] = v;                 // the counts, packed, next to the other counters the host reads
 		}
 		s_before[tid] = before; s_all[tid] = all;
 		__syncthreads();
-		for (int st = 128; st > 0; st >>= 1) {
+		for (int st = EXP_T / 2; st > 0; st >>= 1) {
 			if (tid < st) { s_before[tid] += s_before[tid + st]; s_all[tid] += s_all[tid + st]; }
 			__syncthreads();
 		}
 	}
 	long long base = s_before[0];
 	if (img == 0 && tid == 0) *total = s_all[0];
-	for (int start = 0; start < n; start += 256) {
+	for (int start = 0; start < n; start += EXP_T) {
 		const int i = start + tid;
 		const int cnt = i < n ? ndirs[(long long)img * cap + i] : 0;
 		const int incl = exp_scan_add(cnt);
@@ -512,7 +513,7 @@ __global__ void __launch_bounds__(256) k_expand_oriented(const KeyPoint* refined
 		__syncthreads();
 		int wbase = 0, chunk = 0;
 #pragma unroll
-		for (int w = 0; w < 4; ++w) { const int v = s_wave[w]; wbase += w < wave ? v : 0; chunk += v; }
+		for (int w = 0; w < EXP_T / 64; ++w) { const int v = s_wave[w]; wbase += w < wave ? v : 0; chunk += v; }
 		const long long first = base + wbase + (incl - cnt);
 		if (i < n) {
 			KeyPoint kp = refined[(long long)img * cap + i];
@@ -554,6 +555,6 @@ hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const 
 
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const int* per_image, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap, hipStream_t st) {
-	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(256), 0, st, refined, refined_count, cap, dirs, ndirs, per_image, p.n, total, count_out, oriented, oriented_cap);
+	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(EXP_T), 0, st, refined, refined_count, cap, dirs, ndirs, per_image, p.n, total, count_out, oriented, oriented_cap);
 	return hipGetLastError();
 }

@@ -46,6 +46,7 @@ CASES = [
     ("flat", 0, dict(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1), True),
     ("flat", 0, dict(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1, LAZY_READ=1), True),
     ("flat", 0, dict(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1, MULTIBAND=4), True),
+    ("flat", 0, dict(ESTIMATE_CAMERA=0, TRANS=1, ORDERED_INPUT=1, MULTIBAND=7), True),     # more levels than the one-pass band kernel keeps: a band pass per level
     ("camera", 1, dict(ESTIMATE_CAMERA=0, CYLINDER=1, ORDERED_INPUT=1), False),
     ("camera", 2, dict(), False),
     ("camera", 2, dict(LAZY_READ=1), False),
