@@ -211,6 +211,7 @@ int op_ctx_create(int device, void* hip_stream, op_ctx** out) {
 		OP_FAIL(OP_ERR_UNSUPPORTED, std::string("op_ctx_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
 	op_ctx* c = new op_ctx;
 	c->device = device;
+	c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
 	else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
 	*out = c;

@@ -22,6 +22,7 @@ void op_ctx_release_workspace(op_ctx* c);
 struct ProfStage { std::string label; double total_ms = 0; long calls = 0; };
 struct op_ctx {
 	int device = 0;
+	int num_cu = 256;                                // compute units of the device (sizes the persistent launches)
 	hipStream_t stream = nullptr;
 	bool owns_stream = false;
 	bool profiling = false;
@@ -127,6 +128,7 @@ struct SiftPlan {
 	int src_u8;                 // 0: fp32 sources, 1: uint8 sources (converted like read_img, lib/imgio.cc:54-56)
 	int* zero;                  // batch counters cleared by the first kernel of the step (k_grey_octaves), zero_n ints
 	int zero_n;
+	int num_cu;                 // compute units of the device
 	// Gaussian bank (feature/gaussian.cc:17-40): kern[s][center + k], s = 1..nscale-1
 	float kern[OP_MAX_SCALE][2 * OP_MAX_KCENTER + 1];
 	int kcenter[OP_MAX_SCALE];
@@ -174,9 +176,13 @@ hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t s
 hipError_t launch_pyramid(const SiftPlan& p, int* raw /* n x cap x 4 */, int* raw_count /* n */, int cap, hipStream_t st);
 // debug/staged dump only: mag and ort of one Gaussian plane (GaussianPyramid::cal_mag_ort)
 hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float* mag, float* ort, hipStream_t st);
-hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap,
+// expect = the largest per-image list length seen in the previous batch (0: unknown).  Workgroups cost dispatcher time
+// whether they find work or not (k_refine over the whole 16 K capacity: 4864 workgroups for 30 busy ones per image took
+// 35 us more than a grid sized to the lists), so these two launch as many as the expectation needs; both kernels stride
+// over their lists, any grid is correct.
+hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap, int expect,
 		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
-hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap,
+hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap, int expect,
 		KeyPoint* out, hipStream_t st);
 // per_image[img * OP_OCNT_STRIDE] += orientation peaks of every keypoint (atomic; one counter per 128-byte line; cleared at the start of the step)
 #define OP_OCNT_STRIDE 32

@@ -38,6 +38,7 @@ struct Workspace {
 	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch: source pointer table, counter block
 	std::vector<const void*> srcs_last; void* srcs_dev = nullptr;   // the pointer table the device holds (and where)
 	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
+	int last_raw_max = 0, last_refined_max = 0;      // longest per-image lists of the previous batch: size the refine / sort launches
 	int raw_cap = 16384;                             // per-image capacity of the raw / refined lists; grows on overflow (run_group)
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
@@ -295,13 +296,14 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	int* d_refined_count = d_raw_count + n;
 	int* d_oriented_count = d_raw_count + 2 * n;
 	int* d_ocnt = (int*)W.counts.p + cnt_hdr;
+	plan.num_cu = ctx->num_cu;
 	plan.zero = (int*)W.counts.p; plan.zero_n = (int)(cnt_hdr + (size_t)n * OP_OCNT_STRIDE);      // cleared by k_grey_octaves
 
 	{ ProfScope ps(ctx, "resize + octave grey"); HIPCHK(launch_grey_octaves(plan, keep != nullptr, st)); }
 	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
 	{ ProfScope ps(ctx, "extrema refine");
-	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, (KeyPoint*)W.refinedA.p, d_refined_count, st));
-	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, (KeyPoint*)W.refinedB.p, st)); }
+	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, W.last_raw_max, (KeyPoint*)W.refinedA.p, d_refined_count, st));
+	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, W.last_refined_max, (KeyPoint*)W.refinedB.p, st)); }
 	{ ProfScope ps(ctx, "orientation");
 	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt, st)); }
 
@@ -334,6 +336,8 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	resolve_profile(ctx);
 	W.last_total = total;
 	std::vector<int> raw_count(h_counts, h_counts + n), refined_count(h_counts + n, h_counts + 2 * n);
+	W.last_raw_max = *std::max_element(raw_count.begin(), raw_count.end());
+	W.last_refined_max = *std::max_element(refined_count.begin(), refined_count.end());
 	res.counts.assign(h_counts + 2 * n, h_counts + 3 * n);
 	res.total = total;
 	{
