@@ -76,6 +76,10 @@ int op_ctx_sync(op_ctx* ctx);
  * reference's TotalTimer table (lib/timer.hh:63-83, dumped at exit by main.cc:336); stage labels
  * reuse the reference's ("build pyramid", "extrema", "sift descriptor", "matcher", ...). */
 int op_ctx_set_profiling(op_ctx* ctx, int enable);
+/* Restrict the timing to ONE stage label (NULL or "": all stages).  Every bracketed stage costs two event records and
+ * the gap they put between kernels (measured: 0.05 ms on the 1.05 ms SIFT step with five stages bracketed); a caller
+ * that times its own loop and wants one kernel's duration from inside it brackets that kernel only. */
+int op_ctx_profile_only(op_ctx* ctx, const char* label);
 int op_ctx_profile_reset(op_ctx* ctx);
 int op_ctx_profile_count(op_ctx* ctx);
 int op_ctx_profile_get(op_ctx* ctx, int i, const char** label, double* total_ms, long* calls);

@@ -12,7 +12,7 @@ static hipEvent_t take_event(op_ctx* c) {
 	return e;
 }
 ProfScope::ProfScope(op_ctx* ctx, const char* label): c(ctx) {
-	if (!c->profiling) return;
+	if (!c->profiling || (!c->prof_only.empty() && c->prof_only != label)) return;
 	stage = c->prof_stage(label);
 	a = take_event(c); b = take_event(c);
 	if (a) hipEventRecord(a, c->stream);
@@ -24,9 +24,9 @@ ProfScope::~ProfScope() {
 }
 #include <chrono>
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-HostScope::HostScope(op_ctx* ctx, const char* l): c(ctx), label(l), t0(0) { if (c->profiling) t0 = now_ms(); }
+HostScope::HostScope(op_ctx* ctx, const char* l): c(ctx), label(l), t0(0) { if (c->profiling && c->prof_only.empty()) t0 = now_ms(); }
 HostScope::~HostScope() {
-	if (!c->profiling) return;
+	if (!c->profiling || !c->prof_only.empty()) return;
 	const int st = c->prof_stage(label);
 	c->prof[st].total_ms += now_ms() - t0; c->prof[st].calls += 1;
 }
@@ -52,7 +52,7 @@ struct HostPool {
 	std::mutex run_mu;      // one parallel loop at a time
 	HostPool() {
 		unsigned hw = std::thread::hardware_concurrency();
-		const int nt = (int)std::min<unsigned>(hw ? hw : 4, 32) - 1;
+		const int nt = (int)std::min<unsigned>(hw ? hw : 4, 64) - 1;       // (the RANSAC acceptance epilogue of 640 pairs is ~10 ms of serial work)
 		for (int i = 0; i < nt; ++i) th.emplace_back([this] { worker(); });
 	}
 	void drain() { for (int i; (i = next.fetch_add(1)) < n;) (*body)(i); }
@@ -157,6 +157,11 @@ int op_ctx_set_profiling(op_ctx* c, int enable) {
 	c->profiling = enable != 0;
 	return OP_OK;
 }
+int op_ctx_profile_only(op_ctx* c, const char* label) {
+	if (!c) OP_FAIL(OP_ERR_INVALID, "op_ctx_profile_only: NULL context");
+	c->prof_only = label ? label : "";
+	return OP_OK;
+}
 int op_ctx_profile_reset(op_ctx* c) {
 	if (!c) OP_FAIL(OP_ERR_INVALID, "op_ctx_profile_reset: NULL context");
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -178,7 +183,7 @@ int op_ctx_profile_get(op_ctx* c, int i, const char** label, double* total_ms, l
 }
 
 const char* op_last_error(void) { return g_last_error.c_str(); }
-int op_abi_version(void) { return 4; }      // 3: op_blend_image.mat_h / mat_w; 4: resident match lists, op_sift_batch_host, op_ransac_pairs_multi
+int op_abi_version(void) { return 5; }      // 3: op_blend_image.mat_h / mat_w; 4: resident match lists, op_sift_batch_host, op_ransac_pairs_multi; 5: op_ctx_profile_only
 
 void op_config_default(op_config* c) {
 	// src/config.cfg (every literal goes through a float, lib/config.cc:19-26)

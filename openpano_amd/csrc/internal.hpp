@@ -26,6 +26,7 @@ struct op_ctx {
 	hipStream_t stream = nullptr;
 	bool owns_stream = false;
 	bool profiling = false;
+	std::string prof_only;                           // when not empty: only this stage is bracketed by events
 	std::vector<ProfStage> prof;
 	std::vector<hipEvent_t> ev_pool;                 // recycled events
 	struct Pending { int stage; hipEvent_t a, b; };

@@ -107,6 +107,8 @@ def lib():
     L.op_ctx_destroy.argtypes = [C.c_void_p]
     L.op_ctx_sync.argtypes = [C.c_void_p]
     L.op_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "op_ctx_profile_only"):
+        L.op_ctx_profile_only.argtypes = [C.c_void_p, C.c_char_p]
     L.op_ctx_profile_reset.argtypes = [C.c_void_p]
     L.op_ctx_profile_count.argtypes = [C.c_void_p]
     L.op_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -212,8 +214,12 @@ class Context:
     def sync(self):
         check(lib().op_ctx_sync(self.handle))
 
-    def set_profiling(self, enable=True):
-        check(lib().op_ctx_set_profiling(self.handle, int(enable)))
+    def set_profiling(self, enable=True, only=None):
+        """per-stage HIP-event timing on this context's stream; only = one stage label to bracket (None: all)"""
+        L = lib()
+        if hasattr(L, "op_ctx_profile_only"):
+            check(L.op_ctx_profile_only(self.handle, only.encode() if only else None))
+        check(L.op_ctx_set_profiling(self.handle, int(enable)))
 
     def profile_reset(self):
         check(lib().op_ctx_profile_reset(self.handle))
