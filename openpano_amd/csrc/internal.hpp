@@ -27,6 +27,7 @@ struct op_ctx {
 	bool owns_stream = false;
 	bool profiling = false;
 	std::string prof_only;                           // when not empty: only this stage is bracketed by events
+	int match_slow_seen[2] = {-1, -1};               // exact-scan rows (forward, reverse) of the previous op_match_pairs call: sizes the next launch
 	std::vector<ProfStage> prof;
 	std::vector<hipEvent_t> ev_pool;                 // recycled events
 	struct Pending { int stage; hipEvent_t a, b; };

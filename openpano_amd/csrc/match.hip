@@ -668,6 +668,15 @@ __global__ void __launch_bounds__(256) k_match_sort(const int* __restrict__ pcnt
 
 extern "C" {
 
+// Workgroups of the exact-scan kernel: one per queued row up to 2048 (it strides over longer queues).  The queue length
+// is only known on the device; the previous call's is the estimate (a few dozen rows for a 38-view job: 2048 workgroups
+// that find nothing cost more dispatcher time than the rows take to scan).  A multiple of 8: lin & 7 is the XCD.
+static unsigned slow_grid(int seen) {
+	if (seen < 0) return 2048;
+	const long long want = ((long long)seen + seen / 4 + 64 + 7) & ~7LL;
+	return (unsigned)(want < 2048 ? want : 2048);
+}
+
 int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, const int* pairs, int npairs, op_matches** out) {
 	if (!ctx || !cfg || !f || !pairs || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
@@ -684,6 +693,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	std::vector<WorkItem> work;
 	std::vector<PairDesc> pds(npairs);
 	long long res_rows = 0;
+	size_t n_items = 0;                                                  // row blocks of all pairs = workgroups of a sweep
 	for (int p = 0; p < npairs; ++p) {
 		const int i = pairs[2 * p], j = pairs[2 * p + 1];
 		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) { delete m; OP_FAIL(OP_ERR_INVALID, "op_match_pairs: image index out of range"); }
@@ -695,28 +705,31 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		pd.rev = rev; pd.ia = ia; pd.ib = ib;
 		pd.res_off = (int)res_rows; res_rows += pd.ka;
 		m->lim[2 * (size_t)p] = fv.counts[i]; m->lim[2 * (size_t)p + 1] = fv.counts[j];
+		if (pd.ka > 0 && pd.kb > 0) n_items += (size_t)((pd.ka + 127) / 128);
 	}
-	{	// Workgroups are handed to the 8 XCDs round-robin by index.  The row blocks of one pair (which stream the
-		// same Y set) go to ONE XCD, back to back: Y then comes from HBM once and from that XCD's L2 for the other
-		// row blocks.  Pairs are dealt longest Y first to the XCD with the least work so far, so every XCD's
-		// queue runs from its longest workgroups to its shortest and the last round of the launch is short.
-		std::vector<int> order; order.reserve(npairs);
-		for (int p = 0; p < npairs; ++p) if (pds[p].ka > 0 && pds[p].kb > 0) order.push_back(p);
-		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pds[a].kb > pds[b].kb; });
-		std::vector<WorkItem> chunk[8]; long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int p : order) {
-			int c = 0;
-			for (int k = 1; k < 8; ++k) if (load[k] < load[c]) c = k;
-			const int nrb = (pds[p].ka + 127) / 128;
-			for (int rb = 0; rb < nrb; ++rb) chunk[c].push_back({p, rb});
-			load[c] += (long long)nrb * pds[p].kb;
+	auto build_work_list = [&]() {
+		{	// Workgroups are handed to the 8 XCDs round-robin by index.  The row blocks of one pair (which stream the
+			// same Y set) go to ONE XCD, back to back: Y then comes from HBM once and from that XCD's L2 for the other
+			// row blocks.  Pairs are dealt longest Y first to the XCD with the least work so far, so every XCD's
+			// queue runs from its longest workgroups to its shortest and the last round of the launch is short.
+			std::vector<int> order; order.reserve(npairs);
+			for (int p = 0; p < npairs; ++p) if (pds[p].ka > 0 && pds[p].kb > 0) order.push_back(p);
+			std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pds[a].kb > pds[b].kb; });
+			std::vector<WorkItem> chunk[8]; long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (int p : order) {
+				int c = 0;
+				for (int k = 1; k < 8; ++k) if (load[k] < load[c]) c = k;
+				const int nrb = (pds[p].ka + 127) / 128;
+				for (int rb = 0; rb < nrb; ++rb) chunk[c].push_back({p, rb});
+				load[c] += (long long)nrb * pds[p].kb;
+			}
+			size_t longest = 0, total_items = 0;
+			for (int c = 0; c < 8; ++c) { longest = std::max(longest, chunk[c].size()); total_items += chunk[c].size(); }
+			work.reserve(total_items);
+			for (size_t k = 0; k < longest; ++k)
+				for (int c = 0; c < 8; ++c) if (k < chunk[c].size()) work.push_back(chunk[c][k]);
 		}
-		size_t longest = 0, total_items = 0;
-		for (int c = 0; c < 8; ++c) { longest = std::max(longest, chunk[c].size()); total_items += chunk[c].size(); }
-		work.reserve(total_items);
-		for (size_t k = 0; k < longest; ++k)
-			for (int c = 0; c < 8; ++c) if (k < chunk[c].size()) work.push_back(chunk[c][k]);
-	}
+	};
 	if (res_rows >= (1LL << 30)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: too many rows in one call; split the pair list"); }
 	for (int i = 0; i < fv.n; ++i)
 		if (fv.counts[i] >= (1 << 22)) { delete m; OP_FAIL(OP_ERR_CAPACITY, "op_match_pairs: an image with 4 M descriptors or more (the sweep addresses a descriptor set with 32-bit byte offsets)"); }
@@ -740,7 +753,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	const size_t o_surv = al(o_fb + sizeof(int) * nres);
 	const size_t o_slow = al(o_surv + sizeof(int) * nres);
 	const size_t o_up = al(o_slow + sizeof(int) * 6 * (size_t)slow_cap);       // forward queue, reverse queue, the grouped copy of the one being scanned
-	const size_t up_bytes = sizeof(PairDesc) * npairs + sizeof(WorkItem) * work.size();
+	const size_t up_bytes = sizeof(PairDesc) * npairs + sizeof(WorkItem) * n_items;
 	const size_t arena_bytes = o_up + al(up_bytes);
 	char* arena = nullptr;
 	const size_t hres_bytes = al(sizeof(int) * (3 + (size_t)npairs));
@@ -750,7 +763,6 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 	int* h_res = (int*)pin;                                                // slow_fwd_n, slow_rev_n, match count, matches per pair
 	h_res[0] = h_res[1] = h_res[2] = 0;
 	std::memcpy(pin + hres_bytes, pds.data(), sizeof(PairDesc) * npairs);
-	if (!work.empty()) std::memcpy(pin + hres_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
 #define MCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); rc = OP_ERR_HIP; goto done; } } while (0)
 	MCHK(ctx->match_arena.ensure(arena_bytes));
 	arena = (char*)ctx->match_arena.p;
@@ -758,7 +770,6 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		int* ctrl = (int*)(arena + o_ctrl);
 		int* d_pcnt = ctrl + 4; int* d_fill = ctrl + 4 + 2 * (size_t)npairs; int* d_poff = ctrl + 4 + 3 * (size_t)npairs;
 		MCHK(hipMemsetAsync(ctrl, 0, sizeof(int) * n_ctrl, st));
-		MCHK(hipMemcpyAsync(arena + o_up, pin + hres_bytes, up_bytes, hipMemcpyHostToDevice, st));
 		MatchState S;
 		S.desc = fv.desc; S.split = (const uint4*)(arena + o_split); S.norms = (const float*)(arena + o_norms);
 		S.gmax_bits = (const unsigned*)ctrl; S.pairs = (const PairDesc*)(arena + o_up);
@@ -775,13 +786,18 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 					(uint4*)(arena + o_split), (float*)(arena + o_norms), (unsigned*)ctrl);
 			MCHK(hipGetLastError());
 		}
+		// the split kernel is on its way: the work list (a sort and a deal of the pairs) is built while it runs
+		build_work_list();
+		if (work.size() != n_items) { op_set_error("op_match_pairs: work list size mismatch"); rc = OP_ERR_HIP; goto done; }
+		if (!work.empty()) std::memcpy(pin + hres_bytes + sizeof(PairDesc) * npairs, work.data(), sizeof(WorkItem) * work.size());
+		MCHK(hipMemcpyAsync(arena + o_up, pin + hres_bytes, up_bytes, hipMemcpyHostToDevice, st));
 		if (!work.empty()) {
 			{
 				ProfScope ps(ctx, "matcher mfma forward");
 				hipLaunchKernelGGL(k_match_sweep<false>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
 				MCHK(hipGetLastError());
 				if (grouped) hipLaunchKernelGGL(k_slow_order<false>, dim3(1), dim3(1024), 0, st, S, fv.n);
-				hipLaunchKernelGGL(k_match_slow<false>, dim3(2048), dim3(256), 0, st, S, grouped);
+				hipLaunchKernelGGL(k_match_slow<false>, dim3(slow_grid(ctx->match_slow_seen[0])), dim3(256), 0, st, S, grouped);
 				MCHK(hipGetLastError());
 			}
 			{
@@ -790,7 +806,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 				hipLaunchKernelGGL(k_match_sweep<true>, dim3((unsigned)work.size()), dim3(256), 0, st, S, d_work);
 				MCHK(hipGetLastError());
 				if (grouped) hipLaunchKernelGGL(k_slow_order<true>, dim3(1), dim3(1024), 0, st, S, fv.n);
-				hipLaunchKernelGGL(k_match_slow<true>, dim3(2048), dim3(256), 0, st, S, grouped);
+				hipLaunchKernelGGL(k_match_slow<true>, dim3(slow_grid(ctx->match_slow_seen[1])), dim3(256), 0, st, S, grouped);
 				MCHK(hipGetLastError());
 			}
 			{
@@ -805,6 +821,7 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 		MCHK(hipStreamSynchronize(st));
 		resolve_profile(ctx);                            // (the sort below stays pending until the next resolve: no second wait)
 		if (!work.empty()) {
+			ctx->match_slow_seen[0] = h_res[0]; ctx->match_slow_seen[1] = h_res[1];
 			if (h_res[0] > slow_cap || h_res[1] > slow_cap) {
 				// more rows needed the exact full scan than the queue holds (> 4 M rows of near-duplicate
 				// descriptors in one call): the rows beyond the queue were not matched -- never return that as OP_OK
