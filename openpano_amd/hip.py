@@ -732,25 +732,37 @@ def blend_prepare(cfg, shapes_wh, homos, proj_method, identity_idx):
     return g, hinv, ranges
 
 
+class BlendCall:
+    """``ConnectedImages::blend()`` (stitcher_image.cc:116-155) with the op_blend_geom / op_blend_image arrays marshalled
+    once, like a C host holds them; every call is one op_blend.
+    images: numpy HWC float32 arrays or (device_ptr, h, w); homos: n x 3 x 3 ImageComponent::homo."""
+
+    def __init__(self, ctx: Context, cfg, images, homos, proj_method, identity_idx):
+        self.ctx = ctx
+        n = self.n = len(images)
+        arr_img, self._keep = _mk_images(images)
+        shapes = [(arr_img[i].w, arr_img[i].h) for i in range(n)]
+        self.geom, hinv, ranges = blend_prepare(cfg, shapes, homos, proj_method, identity_idx)
+        arr = self.arr = (OpBlendImage * n)()
+        for i in range(n):
+            arr[i].data = arr_img[i].data; arr[i].h = arr_img[i].h; arr[i].w = arr_img[i].w; arr[i].on_device = arr_img[i].on_device
+            for k in range(9):
+                arr[i].homo_inv[k] = hinv[i, k]
+            for k in range(4):
+                arr[i].range[k] = ranges[i, k]
+        self.ccfg = OpConfig.from_config(cfg)
+        self._fn = lib().op_blend
+
+    def __call__(self) -> Canvas:
+        h = C.c_void_p()
+        check(self._fn(self.ctx.handle, C.byref(self.ccfg), C.byref(self.geom), self.arr, self.n, C.byref(h)))
+        return Canvas(self.ctx, h)
+
+
 def blend(ctx: Context, cfg, images, homos, proj_method, identity_idx) -> Canvas:
     """``ConnectedImages::blend()`` (stitcher_image.cc:116-155) on the device.
     images: numpy HWC float32 arrays or (device_ptr, h, w); homos: n x 3 x 3 ImageComponent::homo."""
-    n = len(images)
-    arr_img, keep = _mk_images(images)
-    shapes = [(arr_img[i].w, arr_img[i].h) for i in range(n)]
-    g, hinv, ranges = blend_prepare(cfg, shapes, homos, proj_method, identity_idx)
-    arr = (OpBlendImage * n)()
-    for i in range(n):
-        arr[i].data = arr_img[i].data; arr[i].h = arr_img[i].h; arr[i].w = arr_img[i].w; arr[i].on_device = arr_img[i].on_device
-        for k in range(9):
-            arr[i].homo_inv[k] = hinv[i, k]
-        for k in range(4):
-            arr[i].range[k] = ranges[i, k]
-    ccfg = OpConfig.from_config(cfg)
-    h = C.c_void_p()
-    check(lib().op_blend(ctx.handle, C.byref(ccfg), C.byref(g), arr, n, C.byref(h)))
-    del keep
-    return Canvas(ctx, h)
+    return BlendCall(ctx, cfg, images, homos, proj_method, identity_idx)()
 
 
 def cyl_warp_shape(cfg, w, h, h_factor, pts=None):
