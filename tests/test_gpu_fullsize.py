@@ -181,8 +181,8 @@ def test_config5_whole_match_job_digest(ctx, oracle, cfg):
     """The whole config-5 job on the device -- 128 device-resident 4000x3000 images, K ~ 4 k descriptors each: SIFT of
     every image against the oracle, then all 8128 pairs in one call -- checked against the exact matcher on the host cores pair by pair (match count +
     order-free digest of the index pairs).  By default a seeded sample of 320 of the 8128 pairs is checked (the
-    oracle needs ~1 core-second per pair); OPENPANO_FULL_C5=1 checks all of them (8 minutes on the GPU box's
-    host: profiles/r02_config5_all_pairs_digest.txt holds that run).  The full check is what found the
+    oracle needs ~1 core-second per pair); OPENPANO_FULL_C5=1 checks all of them and runs RANSAC on all 8128 pairs against
+    the oracle as well (8-9 minutes on the GPU box's host: profiles/r03_config5_all_pairs.txt holds that run).  The full check is what found the
     one-in-740 k reverse exact-scan error of rounds 1-2."""
     import torch
     from openpano_amd import hip
@@ -193,17 +193,25 @@ def test_config5_whole_match_job_digest(ctx, oracle, cfg):
     # SIFT of ALL 128 images against the oracle (descriptors and coordinates, bit for bit)
     want = _pmap(lambda i: oracle.detect_feature((dev_imgs[i].cpu().numpy().astype(np.float64) / 255.0).astype(np.float32)), range(n))
     del dev_imgs
-    descs = []
+    descs, coors = [], []
     for i in range(n):
         d, c = f.get(i)
         assert np.array_equal(d, want[i][0]) and np.array_equal(c, want[i][1]), ("image", i, len(d), len(want[i][0]))
-        descs.append(d)
+        descs.append(d); coors.append(c)
     del want
     pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
-    got = hip.match_pairs(ctx, cfg, f, pairs)
+    mh = hip.match_pairs_handle(ctx, cfg, f, pairs)
+    got = mh.lists()
     assert sum(len(g) for g in got) > 500000
+    full = os.environ.get("OPENPANO_FULL_C5") == "1"
+    if full:
+        # ... and RANSAC of EVERY pair (winner, inlier set, acceptance, confidence, homography) against the oracle's
+        # get_transform under the same injected seeds, from the match lists that never left the device
+        nok = _ransac_job(ctx, oracle, cfg, f, pairs, mh, got, coors, [(4000, 3000)] * n)
+        assert nok > 300, nok
+    mh.free()
     f.free()
-    if os.environ.get("OPENPANO_FULL_C5") == "1":
+    if full:
         sel = list(range(len(pairs)))
     else:
         rng = np.random.default_rng(5)
