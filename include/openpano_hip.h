@@ -176,6 +176,10 @@ int op_debug_math(op_ctx* ctx, int which, const float* x, const float* y, int n,
  * keeps the larger capacity (the reference appends to std::vectors, extrema.cc:36-61).  Exposed so
  * that tests can force the overflow path with a tiny capacity; >= 64. */
 int op_debug_set_raw_capacity(op_ctx* ctx, int cap);
+/* Floats of LDS list arena one sorting pass of the descriptor kernel may use (default and maximum 640).  A batch of 64
+ * window samples (sift.cc:110-146) whose per-bin lists, padded to float4s, need more is sorted and accumulated in two
+ * passes of 32 samples; exposed so that tests can force that path (0: always). */
+int op_debug_set_desc_list_cap(op_ctx* ctx, int floats);
 
 /* =====================================================================================
  * MATCH -- replaces PairWiseMatcher (feature/matcher.hh:40-67, matcher.cc:73-135) as used by

@@ -147,6 +147,7 @@ struct SiftPlan {
 	int calc_offset_depth;
 	float gauss_sigma, scale_factor, ori_radius;
 	int ori_smooth, desc_scale_factor, desc_int_factor;
+	int desc_list_cap;          // k_descriptor: floats of list arena one sorting pass may use (the arena's size; a test lowers it to force the two-pass path)
 };
 
 __host__ __device__ inline long long plane_off_grey(const OctDesc& o) { return o.off; }
@@ -162,6 +163,7 @@ struct KeyPoint {
 	int pad;
 };
 
+#define OP_DESC_LIST_CAP 640   // k_descriptor: floats in the list arena of one batch's counting sort
 #define OP_RW_OWN 240     // k_pyramid_rows: columns owned by a band
 #ifndef OP_RW_SEG
 #define OP_RW_SEG 24      // rows of a segment

@@ -40,6 +40,7 @@ struct Workspace {
 	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
 	int last_raw_max = 0, last_refined_max = 0;      // longest per-image lists of the previous batch: size the refine / sort launches
 	int raw_cap = 16384;                             // per-image capacity of the raw / refined lists; grows on overflow (run_group)
+	int desc_list_cap = OP_DESC_LIST_CAP;            // list arena of the descriptor kernel's sorting pass (op_debug_set_desc_list_cap)
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
 		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); oriented.release();
@@ -229,6 +230,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	// buffers to the observed maximum and re-runs once (the reference has no such limit:
 	// extrema.cc:36-61 appends to std::vectors).  The capacity sticks to the context.
 	const int cap = W.raw_cap;
+	plan.desc_list_cap = W.desc_list_cap;
 
 	// --- buffers
 	HIPCHK(W.ws.ensure(sizeof(float) * (size_t)plan.ws_stride * n));
@@ -536,6 +538,12 @@ int op_sift_batch_host(op_ctx* ctx, const op_config* cfg, const op_image* imgs, 
 int op_debug_set_raw_capacity(op_ctx* ctx, int cap) {
 	if (!ctx || cap < 64) OP_FAIL(OP_ERR_INVALID, "op_debug_set_raw_capacity: bad argument");
 	ctx_workspace(ctx)->raw_cap = cap;
+	return OP_OK;
+}
+
+int op_debug_set_desc_list_cap(op_ctx* ctx, int floats) {
+	if (!ctx || floats < 0 || floats > OP_DESC_LIST_CAP) OP_FAIL(OP_ERR_INVALID, "op_debug_set_desc_list_cap: bad argument");
+	ctx_workspace(ctx)->desc_list_cap = floats;
 	return OP_OK;
 }
 

@@ -144,6 +144,7 @@ def lib():
     L.op_sift_dump_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.op_debug_set_raw_capacity.argtypes = [C.c_void_p, C.c_int]
+    L.op_debug_set_desc_list_cap.argtypes = [C.c_void_p, C.c_int]
     if hasattr(L, "op_match_pairs"):
         L.op_match_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.op_matches_count.argtypes = [C.c_void_p, C.c_int]
@@ -232,6 +233,10 @@ class Context:
             check(lib().op_ctx_profile_get(self.handle, i, C.byref(lab), C.byref(ms), C.byref(calls)))
             out[lab.value.decode()] = (ms.value, calls.value)
         return out
+
+    def set_desc_list_cap(self, floats: int):
+        """test hook: list arena one sorting pass of the descriptor kernel may use (op_debug_set_desc_list_cap)"""
+        check(lib().op_debug_set_desc_list_cap(self.handle, int(floats)))
 
     def set_raw_capacity(self, cap: int):
         """test hook: per-image capacity of the speculative raw / refined lists (op_debug_set_raw_capacity)"""

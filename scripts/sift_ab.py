@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--images", type=int, default=38)
     ap.add_argument("--json", default=None)
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 instead: 128 (or --images) synthetic 4000x3000 uint8 images")
+    ap.add_argument("--no-product", action="store_true", help="only the named libraries (e.g. under a profiler)")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     import numpy as np
@@ -44,7 +45,7 @@ def main():
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    libs = ["product"] + list(a.libs)
+    libs = ([] if a.no_product else ["product"]) + list(a.libs)
     out = {}
     for name in libs:
         path = os.path.join(ROOT, "openpano_amd", "libopenpano_hip.so") if name == "product" else os.path.abspath(name)

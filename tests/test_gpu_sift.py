@@ -265,6 +265,27 @@ def test_raw_capacity_overflow_reruns_instead_of_failing(oracle, cfg):
         c.close()
 
 
+def test_descriptor_two_pass_sort_equals_one_pass(oracle, cfg):
+    """k_descriptor sorts a batch of 64 window samples by bin into a 640-float LDS arena (sift.cc:110-146: the order of
+    every bin's additions is part of the result); a batch whose padded lists would not fit takes two passes of 32
+    samples.  No image of the suite needs that, so it is forced here (arena 0: always two passes; 96 floats: a mix)
+    -- same descriptors, bit for bit."""
+    from openpano_amd import hip
+    imgs = [_view(400, 600, 11), _view(400, 600, 12)]
+    want = [oracle.detect_feature(im) for im in imgs]
+    for arena in (0, 96, 640):
+        c = hip.Context(0)
+        try:
+            c.set_desc_list_cap(arena)
+            f = hip.sift_batch(c, cfg, imgs)
+            for i in range(2):
+                d, co = f.get(i)
+                assert len(d) > 300 and np.array_equal(d, want[i][0]) and np.array_equal(co, want[i][1]), (arena, i)
+            f.free()
+        finally:
+            c.close()
+
+
 def test_host_images_at_a_constant_stride_travel_in_one_copy(ctx, oracle, cfg):
     """Host images that are slices of one array (np.stack: stride == image size; a padded pool: larger stride) take the
     single strided H2D copy of op_sift_batch; separately allocated images take one copy each.  Same features."""
