@@ -147,8 +147,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 		// ---- candidate enumeration.  The reference visits the whole (2 radius + 1)^2 window in (xx outer,
 		// yy inner) order and keeps a sample only inside the circle and the rotated 4 x 4 bin square
 		// (sift.cc:110-126) -- about a third of the window.  Each window column's rows that CAN pass are an
-		// interval, computed here with a safety margin of a row on either side; the exact float tests of
-		// the reference then run on those candidates only, in the reference's order.  Windows wider than 64
+		// interval, computed here with a safety margin (tests/test_descriptor_candidate_intervals.py: 1.02 candidates
+		// per kept sample, none lost); the exact float tests of the reference then run on those candidates only, in
+		// the reference's order.  Windows wider than 64
 		// columns or with more than COLCAP candidates (other DESC_HIST_SCALE_FACTORs) walk the full window.
 		int ncand = nsamp;
 		bool cols = side <= 64;
@@ -158,22 +159,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 				const int xx = lane - radius;
 				const float fxx = (float)xx;
 				const int nowx = kpx + xx;
-				float ylo = -(float)radius, yhi = (float)radius;
-				const float rem = fr2 - fxx * fxx;
-				const float yc = rem > 0.f ? sqrtf(rem) + 1.f : 1.f;
-				ylo = fmaxf(ylo, -yc); yhi = fminf(yhi, yc);
-				// -2.5 <= rot / hist_w <= 1.5 for both rotated coordinates (bin in [-1, 3] after the +1.5 shift)
-				const float m = 0.02f * hist_w + 0.25f;
+				// inside the circle (sift.cc:115, a test on integers):  |yy| <= floor(sqrt(radius^2 - xx^2))
+				const float yc = floorf(sqrtf(fr2 - fxx * fxx) + 1e-3f);
+				float ylo = -yc, yhi = yc;
+				// -2.5 <= rot / hist_w <= 1.5 for both rotated coordinates (bin in [-1, 3] after the +1.5 shift), with a
+				// margin of a twentieth of a pixel and more (the fp32 roundings of either side are below 1e-5 pixels)
+				const float m = 0.005f * hist_w + 0.05f;
 				const float blo = -2.5f * hist_w - m, bhi = 1.5f * hist_w + m;
-				if (fabsf(cosort) > 0.05f) {           // y_rot * hist_w = -xx sin + yy cos
-					const float a = (blo + fxx * sinort) / cosort, b = (bhi + fxx * sinort) / cosort;
+				if (fabsf(cosort) > 0.01f) {           // y_rot * hist_w = -xx sin + yy cos
+					const float rc = 1.f / cosort;
+					const float a = (blo + fxx * sinort) * rc, b = (bhi + fxx * sinort) * rc;
 					ylo = fmaxf(ylo, fminf(a, b)); yhi = fminf(yhi, fmaxf(a, b));
 				}
-				if (fabsf(sinort) > 0.05f) {           // x_rot * hist_w = xx cos + yy sin
-					const float a = (blo - fxx * cosort) / sinort, b = (bhi - fxx * cosort) / sinort;
+				if (fabsf(sinort) > 0.01f) {           // x_rot * hist_w = xx cos + yy sin
+					const float rs = 1.f / sinort;
+					const float a = (blo - fxx * cosort) * rs, b = (bhi - fxx * cosort) * rs;
 					ylo = fmaxf(ylo, fminf(a, b)); yhi = fminf(yhi, fmaxf(a, b));
 				}
-				int ilo = (int)floorf(ylo) - 1, ihi = (int)ceilf(yhi) + 1;
+				int ilo = (int)ceilf(ylo), ihi = (int)floorf(yhi);
 				ilo = ilo < -radius ? -radius : ilo; ihi = ihi > radius ? radius : ihi;
 				ilo = ilo < 1 - kpy ? 1 - kpy : ilo; ihi = ihi > h - 2 - kpy ? h - 2 - kpy : ihi;     // between(nowy, 1, h - 1)
 				if (nowx >= 1 && nowx <= w - 2 && ihi >= ilo) { lo = ilo; len = ihi - ilo + 1; }
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 					xx = (int)(pk & 0xFFu) - radius; yy = (int)(signed char)(pk >> 8) + (i0 + lane - (int)(pk >> 16));
 				} else { xx = qx - radius; yy = qy - radius; }
 				const int nowx = kpx + xx, nowy = kpy + yy;
-				if (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
+				if (cols || (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2)) {      // the intervals lie inside the image
 					const float fxx = (float)xx, fyy = (float)yy;
 					if (!(fxx * fxx + fyy * fyy > fr2)) {
 						float x_rot, y_rot;

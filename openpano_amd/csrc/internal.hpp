@@ -190,8 +190,8 @@ hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int*
 		KeyPoint* out, hipStream_t st);
 // per_image[img * OP_OCNT_STRIDE] += orientation peaks of every keypoint (atomic; one counter per 128-byte line; cleared at the start of the step)
 #define OP_OCNT_STRIDE 32
-hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
-		float* dirs /* n x cap x 36 */, int* ndirs /* n x cap */, int* per_image /* n x OP_OCNT_STRIDE */, hipStream_t st);
+hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap, int expect,
+		float* dirs /* n x cap x 36: histogram in, peak directions out */, int* ndirs /* n x cap */, int* per_image /* n x OP_OCNT_STRIDE */, hipStream_t st);
 // image img's keypoints land at [sum of the earlier images' counts, ...); *total = sum of all, count_out[0..n) = the counts packed
 // (device-side, no host round trip)
 hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,

@@ -279,14 +279,17 @@ __global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const 
 	}
 }
 
-// ---- OrientationAssign::calc_dir (feature/orientation.cc:34-100): one wavefront per keypoint.
-// Samples are evaluated 64 at a time, but each histogram bin is accumulated by ONE lane walking
-// the samples in the reference's (xx outer, yy inner) order, so the fp32 sums round identically.
+// ---- OrientationAssign::calc_dir (feature/orientation.cc:34-100) in two kernels.
+// k_orientation: one wavefront per keypoint builds the 36-bin histogram (:49-66).  Samples are evaluated 64 at a
+// time, but each histogram bin is accumulated by ONE lane walking the samples in the reference's (xx outer, yy inner)
+// order, so the fp32 sums round identically.  k_orient_peaks: one THREAD per keypoint smooths its histogram
+// (:70-75, a recurrence of 2 x 36 dependent steps that no wavefront can share) and picks the peaks (:78-99).
 constexpr int ORI_BINS = 36;
 #ifndef ORI_GRID_X
 #define ORI_GRID_X 512
 #endif
-// The per-image descriptor counters that k_orientation's wavefronts add to lie one per 128-byte line: a thousand
+constexpr int ORI_COLCAP = 1024;     // in-circle samples of one keypoint in the column-interval enumeration (the shipped config needs ~200)
+// The per-image descriptor counters that k_orient_peaks' wavefronts add to lie one per 128-byte line: a thousand
 // atomics per image are nothing, but 38 adjacent counters are ONE line on ONE L2 channel, and 38 000 atomics in a row
 // on it took twice as long as the whole kernel.
 constexpr int OCNT_STRIDE = OP_OCNT_STRIDE;
@@ -302,178 +305,189 @@ __device__ __forceinline__ int ori_scan_add(int v) {
 	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
 	return v;
 }
-__device__ __forceinline__ int ori_max(int v) {
-	int t;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
-	t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
-	return __builtin_amdgcn_readlane(v, 63);
+__device__ __forceinline__ int ori_rank_below(unsigned long long m) {
+	return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+__device__ __forceinline__ int ori_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float ori_uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+#define ORI_FENCE() asm volatile("" ::: "memory")      // one wavefront per workgroup: LDS accesses execute in program order
 
-__global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* refined, const int* refined_count,
-		int cap, float* dirs, int* ndirs, int* per_image) {
+__global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* __restrict__ refined, const int* __restrict__ refined_count,
+		int cap, float* __restrict__ hist_out) {
 	__shared__ unsigned long long s_mask[ORI_BINS];   // per bin: bit l = lane l's sample of this round falls into it
-	__shared__ __attribute__((aligned(16))) float s_sorted[64 + 3 * ORI_BINS + 12];   // the round's values, bin-major, sample order inside a bin; lists 16-byte aligned, zero-padded to float4s
+	__shared__ __attribute__((aligned(16))) float s_sorted[64 + 3 * ORI_BINS + 12 + 4];   // the round's values, bin-major, sample order inside a bin; lists 16-byte aligned, zero-padded to float4s; last float4: zeros
 	__shared__ unsigned short s_off[64];
-	__shared__ float s_hist[ORI_BINS];
+	__shared__ unsigned long long s_startbits[ORI_COLCAP / 64];   // bit e: in-circle sample e is the first of its window column
+	__shared__ unsigned s_colpk[64];                  // k-th non-empty window column: index of its first sample << 16 | (first row & 0xFF) << 8 | column
+	constexpr int ZERO4 = (64 + 3 * ORI_BINS + 12) / 4;
 	const int img = blockIdx.y;
 	const int count = refined_count[img];
 	const int lane = threadIdx.x;
 	const float* base = p.ws + (long long)img * p.ws_stride;
 	const float halfipi = (float)(0.5f / 3.14159265358979323846);
 	if (lane < ORI_BINS) s_mask[lane] = 0ULL;
+	if (lane < 4) s_sorted[ZERO4 * 4 + lane] = 0.f;
 	__syncthreads();
-	int npeaks = 0;                                   // lane 0: orientation peaks of this wavefront's keypoints
 	for (int k = blockIdx.x; k < count; k += gridDim.x) {
 		const KeyPoint kp = refined[(long long)img * cap + k];
-		const OctDesc od = p.oct[kp.oct];
+		const int kpx = ori_uni(kp.x), kpy = ori_uni(kp.y);
+		const OctDesc od = p.oct[ori_uni(kp.oct)];
+		const int w = od.w, h = od.h;
 		// gradient magnitude / orientation of GaussianPyramid::cal_mag_ort (feature/dog.cc:76-84),
 		// evaluated on the Gaussian plane for the window samples only
-		const float* g_img = base + plane_off_gauss(od, p.nscale, kp.scale);
-		const float gauss_weight_sigma = kp.sf * 1.5f;                 // ORI_WINDOW_FACTOR
-		const int rad = (int)roundf(kp.sf * p.ori_radius);
+		const float* g_img = base + plane_off_gauss(od, p.nscale, ori_uni(kp.scale));
+		const float sf = ori_uni(kp.sf);
+		const float gauss_weight_sigma = sf * 1.5f;                 // ORI_WINDOW_FACTOR
+		const int rad = ori_uni((int)roundf(sf * p.ori_radius));
 		const float exp_denom = 2 * (gauss_weight_sigma * gauss_weight_sigma);
 		const int side = 2 * rad, nsamp = side * side;
 		const float frad2 = (float)rad * (float)rad;
-		float h = 0.f;
+		float hsum = 0.f;
+		// ---- the samples the reference keeps (:49-57): window columns xx in [-rad, rad), rows yy in [-rad, rad), inside
+		// the image's interior, inside the circle xx^2 + yy^2 <= rad^2 (a test on integers).  Per column those rows are
+		// an interval, known exactly: the wavefront enumerates only them -- three quarters of the window -- in the
+		// reference's (xx outer, yy inner) order, 64 per round.  Windows wider than 64 columns walk the full window.
+		int ncand = nsamp;
+		bool cols = side <= 64;
+		if (cols) {
+			int lo = 0, len = 0;
+			if (lane < side) {
+				const int xx = lane - rad;
+				const float fxx = (float)xx;
+				const int yc = (int)floorf(sqrtf(frad2 - fxx * fxx) + 1e-3f);       // |yy| <= floor(sqrt(rad^2 - xx^2)); exact for these integers
+				int ilo = -yc, ihi = yc < rad - 1 ? yc : rad - 1;                    // yy < rad
+				ilo = ilo < 1 - kpy ? 1 - kpy : ilo; ihi = ihi > h - 2 - kpy ? h - 2 - kpy : ihi;     // between(newy, 1, h - 1)
+				const int newx = kpx + xx;
+				if (newx >= 1 && newx <= w - 2 && ihi >= ilo) { lo = ilo; len = ihi - ilo + 1; }
+			}
+			const int incl = ori_scan_add(len);
+			ncand = __builtin_amdgcn_readlane(incl, 63);
+			cols = ncand <= ORI_COLCAP;
+			if (cols) {
+				const int start = incl - len;
+				const unsigned long long nonempty = __ballot(len > 0);
+				if (lane < ORI_COLCAP / 64) s_startbits[lane] = 0ULL;
+				ORI_FENCE();
+				if (len > 0) {
+					atomicOr(&s_startbits[start >> 6], 1ULL << (start & 63));
+					s_colpk[ori_rank_below(nonempty)] = ((unsigned)start << 16) | (((unsigned)lo & 0xFFu) << 8) | (unsigned)lane;
+				}
+			} else ncand = nsamp;
+			ORI_FENCE();
+		}
 		// 64 samples per round in the reference's (xx outer, yy inner) order.  The round's values
 		// are sorted by bin with order-free LDS mask ORs and popcount ranks (stable: sample order is
 		// kept inside a bin), then lane b adds bin b's segment in order -- the fp32 sums round like
 		// the sequential  hist[bin] += ...  of orientation.cc:49-66.
 		int qx = lane / (side > 0 ? side : 1), qy = lane % (side > 0 ? side : 1);
-		for (int i0 = 0; i0 < nsamp; i0 += 64) {
+		int kbase = -1;                                  // listed columns started before this round, minus one
+		for (int i0 = 0; i0 < ncand; i0 += 64) {
 			int bin = -1; float val = 0.f;
-			if (i0 + lane < nsamp) {
-				const int xx = qx - rad, yy = qy - rad;
-				const int newx = kp.x + xx, newy = kp.y + yy;
-				if (newx >= 1 && newx <= od.w - 2 && newy >= 1 && newy <= od.h - 2) {
-					const float fxx = (float)xx, fyy = (float)yy;
-					const float r2 = fxx * fxx + fyy * fyy;
-					if (!(r2 > frad2)) {
-						const long long gi = (long long)newy * od.w + newx;
-						const float gdy = g_img[gi + od.w] - g_img[gi - od.w];
-						const float gdx = g_img[gi + 1] - g_img[gi - 1];
-						const float orient = opdev::fast_atan_plus_pi(gdy, gdx);
-						bin = (int)roundf(36 * halfipi * orient);
-						if (bin == ORI_BINS) bin = 0;
-						const float weight = opdev::expf_glibc(-r2 / exp_denom);
-						val = weight * opdev::hypotf_glibc(gdx, gdy);
-					}
+			int ord = 0;
+			if (cols) {
+				const unsigned long long sb = s_startbits[i0 >> 6];
+				ord = kbase + ori_rank_below(sb) + (int)((unsigned)(sb >> lane) & 1u);
+				kbase += __popcll(sb);
+			}
+			if (i0 + lane < ncand) {
+				int xx, yy; bool in;
+				if (cols) {
+					const unsigned pk = s_colpk[ord];
+					xx = (int)(pk & 0xFFu) - rad; yy = (int)(signed char)(pk >> 8) + (i0 + lane - (int)(pk >> 16));
+					in = true;                                                           // the intervals lie inside the image and the circle
+				} else {
+					xx = qx - rad; yy = qy - rad;
+					const int newx = kpx + xx, newy = kpy + yy;
+					in = newx >= 1 && newx <= w - 2 && newy >= 1 && newy <= h - 2;
+				}
+				const float fxx = (float)xx, fyy = (float)yy;
+				const float r2 = fxx * fxx + fyy * fyy;
+				if (in && !(r2 > frad2)) {
+					const int gi = (kpy + yy) * w + (kpx + xx);
+					const float gdy = g_img[gi + w] - g_img[gi - w];
+					const float gdx = g_img[gi + 1] - g_img[gi - 1];
+					const float orient = opdev::fast_atan_plus_pi(gdy, gdx);
+					bin = (int)roundf(36 * halfipi * orient);
+					if (bin == ORI_BINS) bin = 0;
+					const float weight = opdev::expf_glibc(-r2 / exp_denom);
+					val = weight * opdev::hypotf_glibc(gdx, gdy);
 				}
 			}
-			qy += 64;
-			while (qy >= side) { qy -= side; ++qx; }
+			if (!cols) { qy += 64; while (qy >= side) { qy -= side; ++qx; } }
 			if (bin >= 0) atomicOr(&s_mask[bin], 1ULL << lane);
-			__syncthreads();
+			ORI_FENCE();
 			const unsigned long long m = lane < ORI_BINS ? s_mask[lane] : 0ULL;
-			const int c = __popcll(m), pc = (c + 3) & ~3;   // list length, rounded up to whole float4s
-			const int ex = ori_scan_add(pc) - pc;            // exclusive wave scan of the padded bin sizes
-			s_off[lane] = (unsigned short)ex;
+			const int pc = (__popcll(m) + 3) >> 2;             // list length in whole float4s
+			const int ex = ori_scan_add(pc) - pc;              // exclusive wave scan of the padded bin sizes
+			s_off[lane] = (unsigned short)(ex * 16);
 			// +0.0f padding leaves the non-negative fp32 sums unchanged: the list's last float4 is cleared with one 16-byte
-			// write, the scatter below (after the barrier) overwrites the slots that hold values
-			if (pc) *(f32x4*)&s_sorted[ex + pc - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
-			__syncthreads();
-			if (bin >= 0) {
-				const unsigned long long bm = s_mask[bin];
-				s_sorted[s_off[bin] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u))] = val;
-			}
-			__syncthreads();
-			{
-				const f32x4* l = (const f32x4*)&s_sorted[ex];
-				const int T = ori_max(pc);
-				for (int e = 0; e < T; e += 8) {
-					f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-					if (e < pc) a0 = l[e >> 2];
-					if (e + 4 < pc) a1 = l[(e >> 2) + 1];
-					h += a0.x; h += a0.y; h += a0.z; h += a0.w; h += a1.x; h += a1.y; h += a1.z; h += a1.w;
-				}
+			// write (an empty list clears the float4 of zeros), the scatter below overwrites the slots that hold values
+			((f32x4*)s_sorted)[pc ? ex + pc - 1 : ZERO4] = f32x4{0.f, 0.f, 0.f, 0.f};
+			ORI_FENCE();
+			if (bin >= 0) *(float*)((char*)s_sorted + s_off[bin] + ori_rank_below(s_mask[bin]) * 4) = val;
+			ORI_FENCE();
+			for (int e = 0; __ballot(e < pc) != 0ULL; e += 2) {
+				const f32x4 a = ((const f32x4*)s_sorted)[e < pc ? ex + e : ZERO4], c = ((const f32x4*)s_sorted)[e + 1 < pc ? ex + e + 1 : ZERO4];
+				hsum += a.x; hsum += a.y; hsum += a.z; hsum += a.w; hsum += c.x; hsum += c.y; hsum += c.z; hsum += c.w;
 			}
 			if (lane < ORI_BINS) s_mask[lane] = 0ULL;
-			__syncthreads();
+			ORI_FENCE();
 		}
-		// ---- in-place sequential smoothing (orientation.cc:70-75):  hist[i] = hist[i] * 0.5 + (hist[i-1] + hist[i+1]) * 0.25
-		// in double, bins in order, each step reading the ALREADY smoothed left neighbour: a recurrence of 36 dependent
-		// steps per pass.  Walked by one lane through LDS it was more than half of this kernel's instructions (10 VALU +
-		// an LDS round trip per bin).  Here the histogram stays in registers, bin b in lane b, and all lanes run the
-		// recurrence in lockstep: at step t every lane recomputes its bin from the left neighbour's latest value
-		// (DPP wave_shr:1), so after step t bins 0..t are final and stay unchanged.  The double arithmetic of one step is
-		// one fp32 fma:  (double)h * 0.5 and (double)s * 0.25 are exact, and a sum of two fp32-precision terms rounds to
-		// fp32 the same way directly as through a 53-bit intermediate (terms less than 2^29 apart add exactly in double;
-		// further apart, the small one cannot move the large one to or across an fp32 rounding boundary either way), so
-		// float(h * 0.5 + s * 0.25) = fma(s, 0.25f, h * 0.5f) whenever h * 0.5f is exact -- guaranteed by the guard
-		// below (no bin in the denormal neighbourhood); histograms that fail it take the lane-0 walk in double.
-		float hv = lane < ORI_BINS ? h : 0.f;
-		if (__ballot(hv != 0.f && hv < 0x1p-100f) == 0ULL) {
-			for (int K = p.ori_smooth; K--;) {
-				const float half = hv * 0.5f;
-				float nxt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hv), 0x130, 0xF, 0xF, false));   // wave_shl:1: old hist[b + 1]
-				int pv = __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), ORI_BINS - 1);      // lane 0 keeps the old hist[35] (no source lane for it below)
-				float cur = hv;
+		if (lane < ORI_BINS) hist_out[((long long)img * cap + k) * ORI_BINS + lane] = hsum;
+	}
+}
+
+// Smoothing and peaks, one thread per keypoint.  The in-place smoothing (orientation.cc:70-75) is a recurrence: every
+// step reads the ALREADY smoothed left neighbour, 36 dependent steps per pass.  A wavefront per keypoint cannot share
+// them (all 64 lanes wait on one chain: it was a fifth of k_orientation's instructions); with a keypoint per LANE the
+// histogram lives in 36 registers and every lane walks its own chain -- the reference's expression in the reference's
+// types, no reformulation: hist[i] = (float)((double)hist[i] * 0.5 + (double)(prev + next) * 0.25).
+// The raw histogram arrives in, and the peak directions leave through, the same 36 floats per keypoint.
+__global__ void __launch_bounds__(256) k_orient_peaks(const int* __restrict__ refined_count, int cap, int smooth,
+		float* dirs, int* __restrict__ ndirs, int* per_image) {
+	const int img = blockIdx.y;
+	const int count = refined_count[img];
+	int npeaks = 0;
+	for (int k = blockIdx.x * 256 + threadIdx.x; k < count; k += gridDim.x * 256) {
+		float* row = dirs + ((long long)img * cap + k) * ORI_BINS;
+		float hist[ORI_BINS];
 #pragma unroll
-				for (int t = 0; t < ORI_BINS; ++t) {
-					pv = __builtin_amdgcn_update_dpp(pv, __builtin_bit_cast(int, cur), 0x138, 0xF, 0xF, false);     // wave_shr:1: the left neighbour's latest value
-					cur = __builtin_fmaf(__builtin_bit_cast(float, pv) + nxt, 0.25f, half);
-					if (t == 0) {       // bin 35's right neighbour is the NEW hist[0], final after this step
-						const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), 0));
-						nxt = lane == ORI_BINS - 1 ? n0 : nxt;
-					}
-				}
-				hv = lane < ORI_BINS ? cur : 0.f;
-			}
-			if (lane < ORI_BINS) s_hist[lane] = hv;
-			__syncthreads();
-		} else {
-			if (lane < ORI_BINS) s_hist[lane] = h;
-			__syncthreads();
-			if (lane == 0) {
-				for (int K = p.ori_smooth; K--;)
-					for (int i = 0; i < ORI_BINS; ++i) {
-						const float prev = s_hist[i == 0 ? ORI_BINS - 1 : i - 1];
-						const float next = s_hist[i == ORI_BINS - 1 ? 0 : i + 1];
-						s_hist[i] = (float)((double)s_hist[i] * 0.5 + (double)(prev + next) * 0.25);
-					}
-			}
-			__syncthreads();
-			hv = lane < ORI_BINS ? s_hist[lane] : 0.f;
+		for (int i = 0; i < ORI_BINS / 4; ++i) {
+			const f32x4 q = ((const f32x4*)row)[i];
+			hist[4 * i] = q.x; hist[4 * i + 1] = q.y; hist[4 * i + 2] = q.z; hist[4 * i + 3] = q.w;
 		}
-		// the largest bin (orientation.cc:78-80: a running maximum from 0 that a NaN never replaces = v_max_f32 across the wave)
-		float maxbin = hv;
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x111, 0xF, 0xF, false)));
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x112, 0xF, 0xF, false)));
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x114, 0xF, 0xF, false)));
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x118, 0xF, 0xF, false)));
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x142, 0xA, 0xF, false)));
-		maxbin = fmaxf(maxbin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, maxbin), 0x143, 0xC, 0xF, false)));
-		maxbin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, maxbin), 63));
+		for (int K = smooth; K--;) {
+#pragma unroll
+			for (int i = 0; i < ORI_BINS; ++i) {
+				const float prev = hist[i == 0 ? ORI_BINS - 1 : i - 1];
+				const float next = hist[i == ORI_BINS - 1 ? 0 : i + 1];
+				hist[i] = (float)((double)hist[i] * 0.5 + (double)(prev + next) * 0.25);
+			}
+		}
+		float maxbin = 0.f;                                   // :78-80, update_max from 0: a NaN never replaces the maximum
+#pragma unroll
+		for (int i = 0; i < ORI_BINS; ++i) maxbin = hist[i] > maxbin ? hist[i] : maxbin;
 		const float thres = maxbin * 0.8f;                              // ORI_HIST_PEAK_RATIO
-		bool peak = false; float ort = 0.f;
-		if (lane < ORI_BINS) {
-			const float prev = s_hist[lane == 0 ? ORI_BINS - 1 : lane - 1];
-			const float next = s_hist[lane == ORI_BINS - 1 ? 0 : lane + 1];
+		int np = 0;
+#pragma unroll
+		for (int i = 0; i < ORI_BINS; ++i) {
+			const float hv = hist[i];
+			const float prev = hist[i == 0 ? ORI_BINS - 1 : i - 1];
+			const float next = hist[i == ORI_BINS - 1 ? 0 : i + 1];
 			const float mpn = prev < next ? next : prev;
 			if (hv > thres && hv > mpn) {
-				peak = true;
-				double newbin = (double)(float)lane - 0.5 + (double)((hv - prev) / (prev + next - 2 * hv));
+				double newbin = (double)(float)i - 0.5 + (double)((hv - prev) / (prev + next - 2 * hv));
 				if (newbin < 0) newbin += ORI_BINS;
 				else if (newbin >= ORI_BINS) newbin -= ORI_BINS;
-				ort = (float)(newbin / ORI_BINS * 2 * 3.14159265358979323846);
+				row[np++] = (float)(newbin / ORI_BINS * 2 * 3.14159265358979323846);
 			}
 		}
-		const unsigned long long mask = __ballot(peak);
-		const int pos = __popcll(mask & ((1ULL << lane) - 1ULL));
-		float* out = dirs + ((long long)img * cap + k) * ORI_BINS;
-		if (peak) out[pos] = ort;
-		if (lane == 0) {
-			const int np = __popcll(mask);
-			ndirs[(long long)img * cap + k] = np;
-			npeaks += np;
-		}
-		__syncthreads();
+		ndirs[(long long)img * cap + k] = np;
+		npeaks += np;
 	}
-	if (lane == 0 && npeaks) atomicAdd(&per_image[img * OCNT_STRIDE], npeaks);   // the image's descriptor count (order-free), one atomic per wavefront
+	// the image's descriptor count (order-free): one atomic per wavefront
+	const int wave_total = __builtin_amdgcn_readlane(ori_scan_add(npeaks), 63);
+	if ((threadIdx.x & 63) == 0 && wave_total) atomicAdd(&per_image[img * OCNT_STRIDE], wave_total);
 }
 
 // expansion refined -> oriented in (refined order, peak order): OrientationAssign::work (:22-32).  One workgroup per
@@ -551,12 +565,16 @@ hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int*
 	return hipGetLastError();
 }
 
-hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap, int expect,
 		float* dirs, int* ndirs, int* per_image, hipStream_t st) {
 	// ORI_GRID_X wavefronts per image striding over the (device-side) keypoint count, about two keypoints each for the
 	// thousand keypoints of a 1300 x 867 view (measured: 256 / 512 / 1024 / 2048 per image = 0.100 / 0.094 / 0.104 / 0.103 ms)
 	dim3 grid(cap < ORI_GRID_X ? cap : ORI_GRID_X, p.n);
-	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs, ndirs, per_image);
+	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	const int want = expect > 0 ? expect + expect / 4 + 256 : cap;       // the kernel strides: any grid is correct
+	hipLaunchKernelGGL(k_orient_peaks, dim3(((want < cap ? want : cap) + 255) / 256, p.n), dim3(256), 0, st, refined_count, cap, p.ori_smooth, dirs, ndirs, per_image);
 	return hipGetLastError();
 }
 

@@ -307,7 +307,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, W.last_raw_max, (KeyPoint*)W.refinedA.p, d_refined_count, st));
 	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, W.last_refined_max, (KeyPoint*)W.refinedB.p, st)); }
 	{ ProfScope ps(ctx, "orientation");
-	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt, st)); }
+	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, W.last_refined_max, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt, st)); }
 
 	// The descriptor count is only known on the device at this point.  Instead of a round trip,
 	// the output buffers get a capacity predicted from the previous call of this context (x1.25,

@@ -8,17 +8,5 @@ for lib in "$@"; do
   if [ $lib = product ]; then arg=""; else arg="--no-product $lib"; fi
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/${tag}_${name}_sq1 -o pmc -- python scripts/sift_ab.py --steps 2 $arg > gpurun_out/${tag}_${name}_sq1.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_${name}_sq2 -o pmc -- python scripts/sift_ab.py --steps 2 $arg > gpurun_out/${tag}_${name}_sq2.log 2>&1
-  python - <<PY
-import csv, glob, collections
-for ps in ("sq1", "sq2"):
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-    for f in glob.glob("gpurun_out/${tag}_${name}_%s/**/*counter_collection.csv" % ps, recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[(k, r["Counter_Name"])] += 1
-    for k in sorted(agg):
-        if not k.startswith("k_"): continue
-        print("${name}", ps, k, " ".join("%s=%.4g" % (c.replace("SQ_", ""), v / max(cnt[(k, c)], 1)) for c, v in sorted(agg[k].items())))
-PY
+  python scripts/pmc_sift_summary.py ${tag} ${name}
 done
