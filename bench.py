@@ -24,6 +24,9 @@ BASELINE config 5 (128 x 4000x3000 uint8, 8128 pairs: the configuration whose pe
 in the same line; under a weak headline ``strong_config4`` carries the strong-scaled config 4 next to it.
 
 The JSON line also carries
+  configs       BASELINE.json's other configurations, driver-timed in the same invocation (bench_configs.py): "2" (11 ordered
+                600x400), "3" (13 ordered 1500x1112), "4_natural" (config 4 on the natural-texture crops SURVEY 8(d) names;
+                `value_natural` repeats its keypoints+descriptors/s next to `value`), each with its own parity block,
   roofline      live HIP-event timing of the dominant kernel vs its algorithmic HBM bytes,
   cpu_baseline  the reference's CPU path (oracle/_ref when it travelled, else the C oracle) timed
                 on this box's host cores on a bounded sample of the same images (rank 0, N=1),
@@ -64,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-4 section")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-pipeline (ESTIMATE_CAMERA) section")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2, 3 and 4_natural (N = 1 sections)")
     return ap.parse_args(argv)
 
 
@@ -478,11 +482,11 @@ def main():
     dominant = dominant_label
     # algorithmic HBM bytes per launch (DESIGN.md "kernels"), per image:
     alg = {
-        # fused scale space + extrema scan.  ALGORITHMIC bytes as apportioned from SURVEY 8(d) since round 1: grey in, the six DoG
-        # planes out (24 P, read back by the refinement) and what stands in for the reference's mag / ort planes (16 P:
-        # Gaussian scales 1-4).  The kernel as built moves LESS than that: only the Gaussian stack reaches HBM (4 P in,
-        # 24 P out = 28 P) -- `traffic` / `achieved_traffic` next to it say what actually crossed.
-        "build pyramid": 4 * P + 24 * P + 16 * P,
+        # fused scale space + extrema scan: the bytes the kernel must move BY DESIGN -- the grey base of every octave in
+        # (4 P), the six Gaussian planes out (24 P).  The DoG planes never leave LDS and the gradients are re-derived by
+        # the orientation / descriptor kernels, so nothing else is credited here (rounds 1-3 credited this kernel with
+        # 44 P apportioned from SURVEY 8(d)'s whole-path formula: `apportioned_44P` keeps that figure next to it).
+        "build pyramid": 4 * P + 24 * P,
         "resize + octave grey": 12 * H * W + 4 * P,                      # source in, grey octave bases out (working image stays in LDS)
         "sift descriptor": (k_rank / max(nimg, 1)) * (8 * 37 * 37 + 528),        # mag+ort window gathers + output
         "orientation": (k_rank / max(nimg, 1)) * (8 * 16 * 16),
@@ -508,8 +512,13 @@ def main():
         dur_s = stage_ms[name] * 1e-3
         ach = (b * nimg / dur_s / 1e9) if b else None
         tr = pmc.get(name, {}).get("hbm_bytes_per_launch") if isinstance(pmc.get(name), dict) else None
+        extra = {}
+        if name == "build pyramid" and ach:
+            a44 = 44.0 * P * nimg / dur_s / 1e9
+            extra = {"apportioned_44P": {"achieved": a44, "frac": a44 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 44.0 * P * nimg,
+                                         "note": "rounds 1-3's apportionment of SURVEY 8(d): 28 P + 16 P for mag/ort planes this kernel neither computes nor moves"}}
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (ach / HBM_PEAK_GBS) if ach else None,
+                "frac": (ach / HBM_PEAK_GBS) if ach else None, **extra,
                 "traffic": tr,      # rocprofv3 PMC, (2*FETCH_SIZE + WRITE_SIZE) * 1024
                 "traffic_source": pmc_src if tr is not None else None,
                 "achieved_traffic": (tr / dur_s / 1e9) if tr else None,          # the bytes that really crossed HBM / the same time
@@ -547,6 +556,7 @@ def main():
 
     # ---------------- exchange + all-pairs match + RANSAC (ShardedJob; the same code at every N) ----------------
     args.H, args.W = H, W
+    args.pmc, args.pmc_src = pmc, pmc_src          # replayed counters of THIS build (or {}): the matcher's MFMA utilisation
     if hasattr(hip, "match_pairs") and not args.no_match:
         from bench_match import run_job_loops
         out["match"] = run_job_loops(hip, ctx, cfg, feats, n_total, [(W, H)] * n_total, args, dist, dev, rank, world, barrier, log)
@@ -571,6 +581,19 @@ def main():
         from bench_e2e import run_e2e
         out["stitch_e2e"] = run_e2e(hip, ctx, args, log)
 
+    # ---------------- BASELINE configs 2, 3 and 4 on natural texture, same invocation (N=1 only) ----------------
+    if world == 1 and not args.no_configs and not args.no_match:
+        import natural
+        if natural.available():
+            from bench_configs import run_config
+            out["configs"] = {}
+            for key in ("2", "3", "4_natural"):
+                out["configs"][key] = run_config(hip, ctx, key, args, dev, log, parity=not args.no_cpu_baseline)
+            out["value_natural"] = out["configs"]["4_natural"]["keypoints_per_s"]
+            out["value_synthetic"] = value
+        else:
+            log("tests/golden/natural or PIL missing: configs 2, 3, 4_natural skipped")
+
     # ---------------- strong-scaled jobs in the same line: config 4 (N>1, weak headline) and config 5 ----------------
     if not args.no_match:
         from bench_match import run_strong_job
@@ -585,7 +608,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t0 = time.perf_counter()
         out["parity"] = parity_check(hip, ctx, cfg, views, feats, log)
-        out["parity_checked"] = bool(out["parity"]["ok"]) and bool(out.get("config5", {}).get("parity", {"ok": True})["ok"])
+        out["parity_checked"] = (bool(out["parity"]["ok"]) and bool(out.get("config5", {}).get("parity", {"ok": True})["ok"])
+                                 and all(bool(c.get("parity", {"ok": True})["ok"]) for c in out.get("configs", {}).values()))
         out["cpu_baseline"] = cpu_baseline(cfg, views, log)
         if out.get("match"):
             out["match"]["cpu_baseline"] = match_cpu_baseline(cfg, feats, log)

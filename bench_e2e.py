@@ -22,18 +22,15 @@ def _host_lib():
     return lib
 
 
-def run_e2e(hip, ctx, args, log):
-    from openpano_amd import synth
-    from openpano_amd.config import PanoConfig
-    n, H, W = args.images, 867, 1300
-    cfg = PanoConfig(ESTIMATE_CAMERA=1, ORDERED_INPUT=0, TRANS=0)
-    t0 = time.perf_counter()
-    views, focal, Rs = synth.rotating_views(n, H, W, seed=4000, step_deg=14.0, rows=2)
-    log(f"rendered {n} rotating-camera views {W}x{H} in {time.perf_counter() - t0:.1f} s")
+def run_pipeline(hip, ctx, cfg, views, pairs, log, note=None):
+    """One warm and one timed pass of the whole ESTIMATE_CAMERA branch of Stitcher::build() (stitcher.cc:32-64) over
+    `views` (float32 H x W x 3, one size) and the image pairs `pairs` (all pairs: pairwise_match, stitcher.cc:96-113;
+    (i, i + 1 mod n): linear_pairwise_match, :116-136)."""
+    n = len(views)
+    H, W = views[0].shape[:2]
     dev = torch.device("cuda", torch.cuda.current_device())
-    d_imgs = [torch.from_numpy(v).to(dev) for v in views]
+    d_imgs = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in views]
     inputs = [(t.data_ptr(), H, W) for t in d_imgs]
-    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
     shapes = np.array([[W, H]] * n, np.int32)
     host = _host_lib()
 
@@ -64,27 +61,46 @@ def run_e2e(hip, ctx, args, log):
             ij += [[i, j], [j, i]]; conf += [r["confidence"]] * 2; homo += [r["homo"].reshape(9), hinv]
             cnt += [len(inl)] * 2; pts += [np.concatenate([a, b], 1), np.concatenate([b, a], 1)]
         st["pairwise table (host glue)"] = time.perf_counter() - t; t = time.perf_counter()
-        cams = np.zeros((n, 13))
-        host.pano_estimate_cameras(n, shapes.reshape(-1).copy(), len(ij), np.asarray(ij, np.int32).reshape(-1), np.asarray(conf, np.float32),
-                                   np.ascontiguousarray(np.stack(homo)).reshape(-1), np.asarray(cnt, np.int32),
-                                   np.ascontiguousarray(np.concatenate(pts)).reshape(-1), cams.reshape(-1))
-        st["camera estimation + bundle adjustment (host)"] = time.perf_counter() - t; t = time.perf_counter()
-        homos = []
-        for k in range(n):
-            Kc = np.array([[cams[k, 0], 0, cams[k, 2]], [0, cams[k, 0] * cams[k, 1], cams[k, 3]], [0, 0, 1.0]])
-            homos.append(cams[k, 4:].reshape(3, 3).T @ np.linalg.inv(Kc))
-        cv = hip.blend(ctx, cfg, inputs, np.stack(homos), 2, n >> 1)
-        torch.cuda.synchronize()
-        st["blend"] = time.perf_counter() - t
-        res = dict(canvas=[cv.h, cv.w], connected_pairs=len(ij) // 2, inlier_matches=int(sum(cnt) // 2), descriptors=int(feats.total),
-                   focal_estimated=float(np.median(cams[:, 0])), focal_rendered=float(focal))
-        cv.free(); mh.free(); feats.free()
+        res = dict(connected_pairs=len(ij) // 2, inlier_matches=int(sum(cnt) // 2), descriptors=int(feats.total))
+        if ij:
+            cams = np.zeros((n, 13))
+            host.pano_estimate_cameras(n, shapes.reshape(-1).copy(), len(ij), np.asarray(ij, np.int32).reshape(-1), np.asarray(conf, np.float32),
+                                       np.ascontiguousarray(np.stack(homo)).reshape(-1), np.asarray(cnt, np.int32),
+                                       np.ascontiguousarray(np.concatenate(pts)).reshape(-1), cams.reshape(-1))
+            st["camera estimation + bundle adjustment (host)"] = time.perf_counter() - t; t = time.perf_counter()
+            homos = []
+            for k in range(n):
+                Kc = np.array([[cams[k, 0], 0, cams[k, 2]], [0, cams[k, 0] * cams[k, 1], cams[k, 3]], [0, 0, 1.0]])
+                homos.append(cams[k, 4:].reshape(3, 3).T @ np.linalg.inv(Kc))
+            if np.all(np.isfinite(np.stack(homos))):
+                cv = hip.blend(ctx, cfg, inputs, np.stack(homos), 2, n >> 1)
+                torch.cuda.synchronize()
+                st["blend"] = time.perf_counter() - t
+                res.update(canvas=[cv.h, cv.w])
+                cv.free()
+            res.update(focal_estimated=float(np.median(cams[:, 0])))
+        mh.free(); feats.free()
         return st, res
 
     once()                                   # warm-up (allocation pool, kernels)
     st, res = once()
     total = sum(st.values())
-    res.update(images=n, image=[H, W], ms_total=total * 1e3, stage_ms={k: round(v * 1e3, 3) for k, v in st.items()},
-               note="wall clock per stage incl. the Python/ctypes glue of this driver; the reference's own CameraEstimator "
-                    "needs ~10 s for a table of this size (tests/test_camera_vs_ref.py scale), its CPU SIFT ~0.4 s per image-core")
+    res.update(images=n, image=[H, W], image_pairs=len(pairs), ms_total=total * 1e3, stage_ms={k: round(v * 1e3, 3) for k, v in st.items()},
+               note=note or "wall clock per stage incl. the Python/ctypes glue of this driver")
+    return res
+
+
+def run_e2e(hip, ctx, args, log):
+    from openpano_amd import synth
+    from openpano_amd.config import PanoConfig
+    n, H, W = args.images, 867, 1300
+    cfg = PanoConfig(ESTIMATE_CAMERA=1, ORDERED_INPUT=0, TRANS=0)
+    t0 = time.perf_counter()
+    views, focal, Rs = synth.rotating_views(n, H, W, seed=4000, step_deg=14.0, rows=2)
+    log(f"rendered {n} rotating-camera views {W}x{H} in {time.perf_counter() - t0:.1f} s")
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    res = run_pipeline(hip, ctx, cfg, views, pairs, log,
+                       note="wall clock per stage incl. the Python/ctypes glue of this driver; the reference's own CameraEstimator "
+                            "needs ~10 s for a table of this size (tests/test_camera_vs_ref.py scale), its CPU SIFT ~0.4 s per image-core")
+    res["focal_rendered"] = float(focal)
     return res

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 
-def _mfma_roofline(prof, flops):
+def _mfma_roofline(prof, flops, pmc=None, pmc_src=None):
     """forward sweep (every row of the smaller set) + reverse strip (survivors only), both including
     their exact re-score epilogues; algorithmic work = 2*128*Ki*Kj flop per unordered pair"""
     mfma_ms = (prof.get("matcher mfma forward") or 0.0) + (prof.get("matcher mfma reverse") or 0.0)
@@ -29,7 +29,12 @@ def _mfma_roofline(prof, flops):
             "algorithmic_flop_per_launch": flops, "avg_launch_ms": mfma_ms,
             # the clock under matrix load depends on the operand data: bf16 operands like split descriptors sustain
             # 1.93 PFLOP/s on 50 ms launches of nothing but MFMAs (scripts/ubench/mfma_power.hip)
-            "data_ceiling": 1930.0, "frac_of_data_ceiling": 3.0 * alg / 1930.0}
+            "data_ceiling": 1930.0, "frac_of_data_ceiling": 3.0 * alg / 1930.0,
+            # matrix-pipe utilisation from the hardware counters (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) and
+            # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 flop; scripts/gpu_pmc.sh `mfma` pass over a config-4 bench run of this build)
+            "mfma_busy": ((pmc or {}).get("k_match_sweep") or {}).get("mfma_busy"),
+            "mfma_flop_executed_per_launch_config4": ((pmc or {}).get("k_match_sweep") or {}).get("mfma_flop_executed"),
+            "mfma_counter_source": pmc_src if ((pmc or {}).get("k_match_sweep") or {}).get("mfma_busy") is not None else None}
 
 
 def _reduce(dist, dev, tmax_vals, sum_vals):
@@ -81,7 +86,7 @@ def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, 
         "image_pairs": int(npairs), "matches": int(nm), "steps": steps, "ms_per_step": tmax / steps * 1e3,
         "descriptor_allgather_ms": gather_ms, "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None,
         "stage_ms": {k: round(v, 4) for k, v in prof.items()},
-        "roofline": _mfma_roofline(prof, flops),
+        "roofline": _mfma_roofline(prof, flops, getattr(args, "pmc", None), getattr(args, "pmc_src", None)),
     }
     # ---- RANSAC over this rank's pairs (batched TransformEstimation::get_transform + acceptance) ----
     seeds = job.seeds(1)
@@ -241,7 +246,7 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
            "matches_per_s": sm[2] / (phm["match"] * 1e-3), "ransac_image_pairs_per_s": sm[1] / (phm["ransac"] * 1e-3),
            "match_stage_ms": {x: round(v, 4) for x, v in prof.items() if x.startswith("matcher")},
            "sift_stage_ms": {x: round(v, 4) for x, v in prof.items() if not x.startswith("matcher")},
-           "match_roofline": _mfma_roofline(prof, flops),
+           "match_roofline": _mfma_roofline(prof, flops, getattr(args, "pmc", None), getattr(args, "pmc_src", None)),
            "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
     if parity and world == 1:
         t0 = time.perf_counter()

@@ -35,6 +35,7 @@ struct op_matches {
 	int64_t total = 0;
 	int* d_idx = nullptr;              // device, total x (first, second); null when the lists only exist on the host
 	int device = -1; hipStream_t stream = nullptr;       // where d_idx was produced (its producer kernels are ordered on this stream)
+	hipEvent_t produced = nullptr;     // recorded behind the kernel that fills d_idx: the block may only go back to the pool (which is not stream-aware) once it has fired
 	mutable std::vector<int> h_idx;    // host mirror of d_idx, fetched on first use
 	mutable bool host_valid = false;
 	mutable std::mutex mu;
@@ -44,7 +45,9 @@ struct op_matches {
 	std::vector<op_matches*> parts;
 	std::vector<std::vector<int>> part_index;
 	~op_matches() {
-		if (d_idx) { hipSetDevice(device); pool_free(d_idx); }
+		if (d_idx || produced) hipSetDevice(device);
+		if (produced) { hipEventSynchronize(produced); hipEventDestroy(produced); }      // the per-pair sort may still be writing d_idx when the caller frees the result
+		if (d_idx) pool_free(d_idx);
 		for (op_matches* p : parts) delete p;
 	}
 };
@@ -678,9 +681,10 @@ static unsigned slow_grid(int seen) {
 }
 
 int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, const int* pairs, int npairs, op_matches** out) {
-	if (!ctx || !cfg || !f || !pairs || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: bad argument");
+	if (!ctx || !cfg || !f || (!pairs && npairs != 0) || npairs < 0 || !out) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
 	const FeatView fv = op_features_view(f);
+	if (fv.device != ctx->device) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: the features live on another device than the context");
 	hipStream_t st = ctx->stream;
 	const long long total = fv.offsets[fv.n];
 	if (!fv.desc) OP_FAIL(OP_ERR_INVALID, "op_match_pairs: features hold coordinates only (built without descriptors)");
@@ -839,6 +843,8 @@ int op_match_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, cons
 				ProfScope ps(ctx, "matcher result lists");
 				hipLaunchKernelGGL(k_match_sort, dim3((unsigned)npairs), dim3(256), 0, st, (const int*)d_pcnt, (const int*)d_poff, (const int2*)(arena + o_seg), (int2*)m->d_idx);
 				MCHK(hipGetLastError());
+				MCHK(hipEventCreateWithFlags(&m->produced, hipEventDisableTiming));
+				MCHK(hipEventRecord(m->produced, st));
 			}
 		}
 	}

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <numeric>
 #include <thread>
+#include <mutex>
 
 struct op_features;
 struct op_matches;
@@ -21,6 +22,7 @@ struct op_matches;
 int op_features_allgather_blocks(op_ctx* const* ctxs, int nctx, op_features* const* parts, const int* start, int n, op_features** tables);
 int op_features_replicate(op_ctx* dst, const op_features* f, op_features** out);
 std::vector<op_features*>& op_features_replicas(op_features* f);
+int op_features_device(const op_features* f);
 op_matches* op_matches_merge(op_matches* const* parts, const std::vector<std::vector<int>>& index, int npairs);
 const std::vector<op_matches*>& op_matches_parts(const op_matches* m);
 const std::vector<std::vector<int>>& op_matches_part_index(const op_matches* m);
@@ -101,8 +103,15 @@ int op_sift_batch_multi(op_group* g, const op_config* cfg, const op_image* imgs,
 // the table of f on every device of the group: replicas made by op_sift_batch_multi, or pulled from f's device now
 // (in parallel, one host thread per destination) and kept with f
 static int ensure_replicas(op_group* g, const op_features* f, int nd) {
+	// the replicas are cached on f by slot; a slot is only reused for the device it was made for (the same features
+	// may meet a group of other devices, or the same devices in another order), and f itself must be slot 0's table
+	static std::mutex rep_mu;
+	std::lock_guard<std::mutex> lk(rep_mu);
+	if (op_features_device(f) != g->ctxs[0]->device) OP_FAIL(OP_ERR_INVALID, "op_group: the features do not live on the group's first device");
 	std::vector<op_features*>& rep = op_features_replicas(const_cast<op_features*>(f));
 	if (rep.size() < g->ctxs.size()) rep.resize(g->ctxs.size(), nullptr);
+	for (int k = 1; k < nd; ++k)
+		if (rep[k] && op_features_device(rep[k]) != g->ctxs[k]->device) { op_features_free(rep[k]); rep[k] = nullptr; }
 	std::vector<int> rcs(nd, OP_OK);
 	std::vector<std::string> errs(nd);
 	std::vector<std::thread> th;

@@ -541,7 +541,7 @@ extern "C" {
 int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, const op_matches* mt,
 		const int* pairs, int npairs, const int* shapes_wh, const uint32_t* seeds, uint32_t base_seed,
 		op_ransac_result** out) {
-	if (!ctx || !cfg || !f || !mt || !pairs || npairs < 0 || !shapes_wh || !out) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: bad argument");
+	if (!ctx || !cfg || !f || !mt || (!pairs && npairs != 0) || npairs < 0 || !shapes_wh || !out) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: bad argument");
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
 	const FeatView fv = op_features_view(f);

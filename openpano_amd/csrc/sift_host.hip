@@ -702,6 +702,7 @@ int op_features_replicate(op_ctx* dst, const op_features* src, op_features** out
 	return OP_OK;
 }
 std::vector<op_features*>& op_features_replicas(op_features* f) { return f->replicas; }
+int op_features_device(const op_features* f) { return f->device; }
 
 extern "C" {
 

@@ -223,6 +223,9 @@ class HipEngine:
 
     def table(self, desc, coor, counts):
         """image-indexed feature table in this rank's HBM: the library adopts the exchanged buffers (no copy)"""
+        if int(desc.shape[0]) == 0:                     # a job without a single descriptor: the library wants real pointers
+            desc = torch.zeros((1, 128), dtype=torch.float32, device=self.device)
+            coor = torch.zeros((1, 2), dtype=torch.float64, device=self.device)
         return self.hip.Features.adopt_device(self.ctx, desc.data_ptr(), counts, coor.data_ptr(), keep=(desc, coor))
 
     def match(self, table, pairs):
@@ -275,6 +278,12 @@ class ShardedJob:
 
     def sift(self, local_images):
         assert callable(local_images) or len(local_images) == len(self.local_ids)
+        # a single-rank table ADOPTS the engine's feature buffers, which the next sift() frees: results of the previous
+        # generation go first, nothing may match against memory that is back in the pool
+        if self.mh is not None:
+            self.e.free(self.mh); self.mh = None
+        if self.tab is not None:
+            self.e.free(self.tab); self.tab = None
         self.desc, self.coor, self.counts = self.e.sift(local_images)
         return sum(self.counts)
 

@@ -21,7 +21,7 @@ root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 LABELS = {"k_grey_octaves": "resize + octave grey", "k_pyramid": "build pyramid", "k_pyramid_rows": "build pyramid",
           "k_extrema_scan": "extrema scan", "k_refine": "extrema refine", "k_sort_refined": "extrema refine",
           "k_orientation": "orientation", "k_descriptor": "sift descriptor",
-          "k_match_top4": "matcher mfma top4", "k_match_decide": "matcher decide", "k_norms": "matcher norms",
+          "k_match_sweep": "matcher mfma sweep", "k_match_slow": "matcher exact scan", "k_split_bf16": "matcher split", "k_orient_peaks": "orientation peaks",
           "k_ransac_hyp": "ransac", "k_blend_linear": "blend linear"}
 
 
@@ -42,6 +42,8 @@ for d in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_*"))):
                 if c is None or v is None:
                     continue
                 a = acc[k][c]; a[0] += float(v); a[1] += 1
+                if c == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):      # the pass's own dispatch durations: what GRBM_GUI_ACTIVE is a count of
+                    a = acc[k]["_gui_pass_ns"]; a[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); a[1] += 1
 out = {}
 for k, cs in acc.items():
     e = {c: s / max(n, 1) for c, (s, n) in cs.items()}
@@ -49,6 +51,15 @@ for k, cs in acc.items():
     if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = (2.0 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024.0
         e["hbm_bytes_per_launch_uncorrected"] = (e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024.0
+    if e.get("SQ_VALU_MFMA_BUSY_CYCLES") and e.get("GRBM_GUI_ACTIVE"):
+        # MfmaUtil (counter_defs.yaml): matrix-pipe busy cycles summed over the SIMDs / (kernel cycles x 1024 SIMDs).  Whether
+        # rocprofv3 hands GRBM_GUI_ACTIVE per device or summed over its 8 XCDs is read off the data: cycles per nanosecond of the
+        # dispatch must be a shader clock (1.5 - 2.5 GHz), not eight of them
+        per_ns = e["GRBM_GUI_ACTIVE"] / max(e.get("_gui_pass_ns", 0.0), 1.0)
+        xcd_sum = 8.0 if per_ns > 6.0 else 1.0
+        e["gui_active_cycles_per_ns"] = per_ns / xcd_sum
+        e["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / xcd_sum * 1024.0)
+        e["mfma_flop_executed"] = e.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512.0
     if e.get("SQ_BUSY_CYCLES") and e.get("SQ_ACTIVE_INST_VALU"):
         e["valu_active_over_wave_cycles"] = e["SQ_ACTIVE_INST_VALU"] / max(e.get("SQ_WAVE_CYCLES", 1.0), 1.0)
     out[k] = e
