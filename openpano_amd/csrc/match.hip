@@ -124,7 +124,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct WorkItem { int pair, rowblock; };
 struct PairDesc { int a_off, ka, b_off, kb; int res_off; int rev; int ia, ib; };   // ia / ib: image indices of the A / B set (the exact-scan queue is grouped by the image it scans)
 
-constexpr int YP = 132;   // LDS pitch of a Y tile row (floats): 16-B slot rotation -> conflict-free b128
+// LDS image of a Y tile: 32 split rows of 512 bytes, LINEAR (the tile arrives by LDS-DMA, whose destination is
+// wave base + lane x 16 bytes), with the 16-byte blocks of row r stored at position (block ^ (r & 15)): the lanes of one
+// ds_read_b128 group read the same logical block of 16 different rows, i.e. 16 different positions -> conflict-free.
+constexpr int YROW = 128;  // floats per tile row in LDS
 
 // Two-term bf16 split of every descriptor, row r -> [128 x hi][128 x lo] (512 B): hi = bf16(v)
 // (round to nearest even), lo = bf16(v - hi); v - hi is exact in fp32, so |v - hi - lo| <= 2^-18 |v|.
@@ -172,6 +175,9 @@ __global__ void __launch_bounds__(256) k_split_bf16(const float* __restrict__ de
 	if (threadIdx.x == 0) atomicMax(gmax_bits, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 }
 
+#ifndef MATCH_WAVES
+#define MATCH_WAVES 4      // resident wavefronts per SIMD = workgroups per CU (33 KB of LDS each)
+#endif
 constexpr int NK = 4;      // kept entries per lane half (descending); a half whose NK entries all tie within the error margin sends its row to the exact full scan
 
 // The sweep's running top-NK is kept on KEYS: the score with its low 4 mantissa bits replaced by the MFMA
@@ -280,11 +286,15 @@ __device__ __forceinline__ void finish_reverse(const MatchState& S, const PairDe
 // distance; a row one of whose halves has all 4 kept entries inside the margin is queued for an
 // exact full scan instead.
 template <bool REV>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
-	__shared__ __attribute__((aligned(16))) float s_y[2][32 * YP];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_WAVES, MATCH_WAVES))) k_match_sweep(MatchState S, const WorkItem* __restrict__ work) {
+	// two tile images as two OBJECTS (not one array indexed by the parity of the tile): the wait-count pass holds an LDS
+	// read back behind a pending LDS-DMA unless it can tell their destinations apart, and it can for distinct variables
+	__shared__ __attribute__((aligned(1024))) float s_y0[32 * YROW];
+	__shared__ __attribute__((aligned(1024))) float s_y1[32 * YROW];
 	__shared__ __attribute__((aligned(16))) float s_nyh[2][32];
-	__shared__ float s_ms[4][32][2][NK];
-	__shared__ int s_mi[4][32][2][NK];
+	// the lane halves' top-4 lists of the epilogue take the place of the first tile image (dead once the sweep has ended)
+	float (*s_ms)[32][2][NK] = (float (*)[32][2][NK])s_y0;
+	int (*s_mi)[32][2][NK] = (int (*)[32][2][NK])(s_y0 + 4 * 32 * 2 * NK);
 	const WorkItem wk = work[blockIdx.x];
 	const PairDesc pd = S.pairs[wk.pair];
 	const int nrows = REV ? S.nsurv[wk.pair] : pd.ka;
@@ -309,8 +319,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	for (int kb = 0; kb < 8; ++kb) { xh[kb] = XS[2 * kb + h]; xl[kb] = XS[16 + 2 * kb + h]; }
 	// The X fragments must have LANDED before the tile loop: a load still pending at the loop header makes
 	// the compiler's wait-count pass put `s_waitcnt vmcnt(0/1)` in front of the MFMAs that read it in EVERY
-	// iteration, and since the counter is in order that drains the next tile's prefetch in the middle of
-	// the MFMA chain.  Using the registers here forces the wait once, outside the loop.
+	// iteration.  Using the registers here forces the wait once, outside the loop.
 #pragma unroll
 	for (int kb = 0; kb < 8; ++kb) asm volatile("" :: "v"(xh[kb].x), "v"(xl[kb].x));
 	float ts[NK]; int ti[NK];
@@ -318,48 +327,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 	for (int r = 0; r < NK; ++r) { ts[r] = -FLT_MAX; ti[r] = -1; }
 	const int ntiles = (ky + 31) / 32;
 
-	// global -> registers and registers -> LDS are split so that the next tile's loads are in flight
-	// while the MFMAs of the current tile run; the LDS store happens after them
-	// Four 16-byte blocks per thread and tile, in four named registers (an array here ended up in scratch
-	// memory once the loads lost their predication).  No exec-mask branches: rows past the end of Y
-	// re-read its last row, their columns cannot rank because their |y|^2/2 is FLT_MAX.
-	uint4 st0, st1, st2, st3; float stage_ny = 0.f; bool stage_pad = false;
-	const int f_yr = tid >> 5, f_c4 = tid & 31;          // block e = tid + 256 r  ->  row f_yr + 8 r, column block f_c4
-	// 32-bit byte offsets from the (uniform) base of the Y split: the loads take the SGPR-base + VGPR-offset form,
-	// a row clamp is one v_min on the offset (op_match_pairs refuses sets of 4 M descriptors and more)
-	const char* ys_base = (const char*)YS;
-	const unsigned f_last = (unsigned)(ky - 1) * 512u + (unsigned)f_c4 * 16u;
-	const unsigned f_first = (unsigned)f_yr * 512u + (unsigned)f_c4 * 16u;
-	auto fetch_tile = [&](int t) {
-		const unsigned o0 = f_first + (unsigned)t * 16384u;
-		const unsigned g0 = o0 < f_last ? o0 : f_last, g1 = o0 + 4096u < f_last ? o0 + 4096u : f_last,
-				g2 = o0 + 8192u < f_last ? o0 + 8192u : f_last, g3 = o0 + 12288u < f_last ? o0 + 12288u : f_last;
-		st0 = *(const uint4*)(ys_base + g0);
-		st1 = *(const uint4*)(ys_base + g1);
-		st2 = *(const uint4*)(ys_base + g2);
-		st3 = *(const uint4*)(ys_base + g3);
+	// The Y tiles stream from HBM straight into LDS (buffer_load_dwordx4 ... lds: no staging registers, no address
+	// arithmetic and no ds_write per tile): a tile is 16 wave-instructions of 1 KB, four per wavefront.  Instruction
+	// q of wave w fills LDS rows 8 w + 2 q and + 1; lane L lands on 16-byte position (L & 31) of row 8 w + 2 q + (L >> 5),
+	// so it FETCHES that row's block (L & 31) ^ (row & 15) -- the permutation the MFMA operand reads undo.  The tile
+	// number goes into the instruction's scalar offset; rows past the end of Y lie outside the buffer descriptor and
+	// read as zeros (their columns cannot rank: -|y|^2/2 is -FLT_MAX there).
+	const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(YS), 0, (unsigned)ky * 512u, 0x00020000);
+	// r & 15 = (8 w & 8) | 2 q | (L >> 5) without carries, so the fetched block is ((L & 31) ^ (8 w & 8) ^ (L >> 5)) ^ 2 q: ONE offset
+	// register, piece q differs by an XOR of 32 q bytes and by 1024 q bytes that go into the instruction's immediate offset
+	// (which moves the LDS destination by the same 1024 q: exactly where piece q belongs)
+	const unsigned dma_off = (8u * (unsigned)wave + (unsigned)(lane >> 5)) * 512u + ((((unsigned)lane & 31u) ^ ((8u * (unsigned)wave) & 8u) ^ (unsigned)(lane >> 5)) << 4);
+	float stage_ny = 0.f; bool stage_pad = false;
+	auto fetch_tile = [&](int t, float* image) {
+		__attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(image + 4 * wave * 256);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(ysrc, dst, 16, dma_off, t * 16384, 0, 0);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(ysrc, dst, 16, dma_off ^ 32u, t * 16384, 1024, 0);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(ysrc, dst, 16, dma_off ^ 64u, t * 16384, 2048, 0);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(ysrc, dst, 16, dma_off ^ 96u, t * 16384, 3072, 0);
 		// the raw |y|^2 only: any arithmetic on it here would wait for the load at the top of the iteration
 		const int gy = t * 32 + (tid & 31);
 		stage_ny = ny[gy < ky ? gy : ky - 1];
 		stage_pad = gy >= ky;
 	};
 	auto commit_tile = [&](int buf) {
-		float* d = &s_y[buf][f_yr * YP + f_c4 * 4];
-		*(uint4*)(d) = st0;
-		*(uint4*)(d + 8 * YP) = st1;
-		*(uint4*)(d + 16 * YP) = st2;
-		*(uint4*)(d + 24 * YP) = st3;
 		if (tid < 32) s_nyh[buf][tid] = stage_pad ? -FLT_MAX : -0.5f * stage_ny;   // -|y|^2/2: the accumulators START from it; padded columns can never rank
 	};
+	// this lane's operand blocks in a tile image: row j, logical block 2 kb + h (hi) and 16 + 2 kb + h (lo: + 256 bytes), i.e.
+	// byte (j * 512 + ((h ^ (j & 15)) << 4)) ^ (32 kb) -- one register and one XOR per block (the images are 1 KB-aligned)
+	const unsigned yoff0 = (unsigned)j * 512u + (((unsigned)h ^ ((unsigned)j & 15u)) << 4);
 
-	fetch_tile(0);
-	commit_tile(0);
-	__syncthreads();
-	for (int t = 0; t < ntiles; ++t) {
-		const int buf = t & 1;
-		if (t + 1 < ntiles) fetch_tile(t + 1);
+	// one tile: start the DMA of the next one into the OTHER image, MFMA chain + top-4 on this one
+	auto tile_step = [&](int t, const float* ytile, float* other, int buf) {
+		if (t + 1 < ntiles) fetch_tile(t + 1, other);
 		STAMP(0);
-		const uint4* yrow = (const uint4*)&s_y[buf][j * YP];      // [16 x hi][16 x lo] 16-byte blocks of tile row j
 		// the accumulators start from -|y|^2/2 of this lane's 16 columns i = (reg&3) + 8*(reg>>2) + 4*h (four
 		// 16-byte LDS reads straight into the accumulator registers): the MFMA chain ends on the scores
 		f32x16 acc;
@@ -372,7 +373,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		// DESIGN.md section 6)
 #pragma unroll
 		for (int kb = 0; kb < 8; ++kb) {
-			const bf16x8 ah = __builtin_bit_cast(bf16x8, yrow[2 * kb + h]), al = __builtin_bit_cast(bf16x8, yrow[16 + 2 * kb + h]);
+			const char* blk = (const char*)ytile + (yoff0 ^ (32u * (unsigned)kb));
+			const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)blk), al = __builtin_bit_cast(bf16x8, *(const uint4*)(blk + 256));
 			const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[kb]), bl = __builtin_bit_cast(bf16x8, xl[kb]);
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
@@ -389,8 +391,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 		STAMP(2);
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		STAMP(3);
-		__syncthreads();
+		__syncthreads();                              // (carries the wait for this wavefront's DMA pieces of tile t + 1)
 		STAMP(4);
+	};
+	fetch_tile(0, s_y0);
+	commit_tile(0);
+	__syncthreads();
+	for (int t = 0; t < ntiles; t += 2) {
+		tile_step(t, s_y0, s_y1, 0);
+		if (t + 1 < ntiles) tile_step(t + 1, s_y1, s_y0, 1);
 	}
 	// (tile, slot) -> column: slot reg of lane half h is column (reg & 3) + 8 (reg >> 2) + 4 h of its tile; never-filled
 	// entries (tile -1) and the padded columns of the last tile (score -FLT_MAX, they rank above nothing real) are no candidates
