@@ -43,7 +43,10 @@
 #include "stitch/homography.hh"
 #include "stitch/imageref.hh"
 #include "stitch/stitcher_image.hh"
+#include "stitch/camera.hh"
 #include "lib/debugutils.hh"
+#include "lib/timer.hh"
+#include "pano_host.h"
 #else
 #include "pano_types.hh"
 #include "pano_camera.hh"
@@ -612,6 +615,53 @@ inline void ConnectedImages::prepare(bool set_inverse, bool set_range) {
 	}
 }
 inline Mat32f ConnectedImages::blend() const { return hip_blend(*this); }
+#endif
+
+#ifdef OPENPANO_WITH_REFERENCE
+// Hook 6 (HOST-ONLY, optional): CameraEstimator{pairwise_matches, shapes}.estimate() of Stitcher::estimate_camera
+// (stitch/stitcher.cc:143-146 -> camera_estimator.cc:46-103 -> incremental_bundle_adjuster.cc:117-385) through
+// libpano_host.so, the Eigen-free estimator of host/pano_camera.hh: same constructor arguments, same estimate().  The
+// reference's bundle adjuster materialises and zeroes a (2 x matches) x (6 x images) Jacobian per iteration
+// (incremental_bundle_adjuster.cc:280); the mirror accumulates J^T J block by block in the reference's summation order --
+// the cameras are the reference's, digit for digit (tests/test_camera_vs_ref.py; both sides then solve through the same
+// QR / SVD arithmetic, i.e. parity is unpinned at Eigen's own rounding only).  Unlike the reference class this one does
+// not write back into `matches` (camera_estimator.hh:33); Stitcher::build() clears them right after (stitcher.cc:54).
+class HostCameraEstimator {
+	public:
+		HostCameraEstimator(std::vector<std::vector<MatchInfo>>& matches, const std::vector<Shape2D>& image_shapes):
+			matches(matches), shapes(image_shapes) {}
+		std::vector<Camera> estimate() {
+			GuardedTimer tm("Estimate Camera");                  // the reference's own label (camera_estimator.cc:47)
+			pano_config_set("STRAIGHTEN", (float)config::STRAIGHTEN); pano_config_set("MULTIPASS_BA", (float)config::MULTIPASS_BA);
+			pano_config_set("LM_LAMBDA", (float)config::LM_LAMBDA); pano_config_set("ESTIMATE_CAMERA", (float)config::ESTIMATE_CAMERA);
+			pano_config_set("ORDERED_INPUT", (float)config::ORDERED_INPUT); pano_config_set("TRANS", (float)config::TRANS);
+			pano_config_set("CYLINDER", (float)config::CYLINDER);
+			const int n = (int)matches.size();
+			std::vector<int> wh, ij, cnt; std::vector<float> conf; std::vector<double> homo, pts;
+			for (auto& s : shapes) { wh.push_back(s.w); wh.push_back(s.h); }
+			for (int i = 0; i < n; ++i)
+				for (int j = 0; j < n; ++j) {
+					const MatchInfo& m = matches[i][j];
+					if (m.match.empty() && m.confidence == 0) continue;           // never assigned by match_image (stitcher.cc:79-93)
+					ij.push_back(i); ij.push_back(j); conf.push_back(m.confidence); cnt.push_back((int)m.match.size());
+					for (int k = 0; k < 9; ++k) homo.push_back(m.homo[k]);
+					for (auto& p : m.match) { pts.push_back(p.first.x); pts.push_back(p.first.y); pts.push_back(p.second.x); pts.push_back(p.second.y); }
+				}
+			std::vector<double> out((size_t)n * 13);
+			if (pts.empty()) pts.push_back(0);
+			pano_estimate_cameras(n, wh.data(), (int)cnt.size(), ij.data(), conf.data(), homo.data(), cnt.data(), pts.data(), out.data());
+			std::vector<Camera> cams(n);
+			for (int i = 0; i < n; ++i) {
+				const double* o = out.data() + 13 * (size_t)i;
+				cams[i].focal = o[0]; cams[i].aspect = o[1]; cams[i].ppx = o[2]; cams[i].ppy = o[3];
+				for (int k = 0; k < 9; ++k) cams[i].R[k] = o[4 + k];
+			}
+			return cams;
+		}
+	private:
+		std::vector<std::vector<MatchInfo>>& matches;
+		const std::vector<Shape2D>& shapes;
+};
 #endif
 
 // CylinderWarper (stitch/warp.hh:42-61): same method set

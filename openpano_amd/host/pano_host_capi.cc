@@ -8,6 +8,10 @@
 
 using namespace pano;
 
+// Only the C entry points leave this library (built with -fvisibility=hidden): its classes carry the REFERENCE's names
+// (pano::Camera, pano::CameraEstimator, ...) and it is loaded into processes that contain the reference's own classes of
+// those names (the hooked CLI, oracle/ref_stitch_test) -- exported, the two sets would interpose each other.
+#pragma GCC visibility push(default)
 extern "C" {
 
 int pano_config_set(const char* key, float v) {
@@ -97,3 +101,4 @@ int pano_homography_inverse(const double* a, double* inv) {
 void pano_colpiv_solve(const double* A, int n, const double* b, double* x) { pano_la::colpiv_qr_solve(A, n, b, x); }
 
 }	// extern "C"
+#pragma GCC visibility pop

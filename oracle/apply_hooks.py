@@ -15,6 +15,8 @@ and writes two edited variants under the output directory (oracle/_ref/variants,
              3  TransformEstimation(...)            -> HipTransformEstimation(...)         (stitcher.cc, cylstitcher.cc)
              4  bundle.blend()                      -> hip_blend(bundle)                   (stitcher.cc, cylstitcher.cc)
              5  CylinderWarper warper(...)          -> HipCylinderWarper warper(...)       (cylstitcher.cc)
+           hipfast/ additionally carries INTEGRATION.md's batched forms (1b, 2b, 3b) and the optional HOST hook
+             6  CameraEstimator{...}.estimate()     -> HostCameraEstimator{...}.estimate() (stitcher.cc)
 
 So that both variants and the untouched reference classes can live in ONE test process, the three classes are
 renamed per variant (Stitcher -> ExactStitcher / HookedStitcher, ...).  A maintainer applying the hooks to the
@@ -93,6 +95,13 @@ def variant_hip(name, text, prefix="Hooked", fast=False):
         te = "HipBatchedTransformEstimation" if (fast and name == "stitcher.cc") else "HipTransformEstimation"   # hook 3 / 3b
         text = must_sub(r"(?<![\w:])TransformEstimation(\s*\(|\s+transf\s*\()", te + r"\1", text, name)
         text = must_sub(r"\bbundle\.blend\(\)", "hip_blend(bundle)", text, name)                            # hook 4
+    if name == "stitcher.cc" and fast:
+        text = must_sub(r"\bCameraEstimator\{", "HostCameraEstimator{", text, name)                        # hook 6 (host-only, optional)
+        # hook 2b, second half: with every pair already matched and estimated by the matcher object, the bodies of the two pair
+        # loops (stitcher.cc:106-109, :120-134) are table lookups, and run in parallel they do nothing but race in the reference's
+        # print_debug (lib/debugutils.cc:33-38 inserts into a static std::map outside its critical section; under -DDEBUG 703
+        # near-simultaneous calls corrupt it -- seen as a segfault in match_image and as free() aborts at exit): serial loops
+        text = must_sub(r"#pragma omp parallel for schedule\(dynamic\)\s*\n(\s*REP\((?:k, \(int\)tasks\.size\(\)|i, n)\))", r"\1", text, name, 2)
     if name == "cylstitcher.cc":
         text = must_sub(r"\bCylinderWarper warper\b", "HipCylinderWarper warper", text, name, 2)            # hook 5
     return text

@@ -9,7 +9,9 @@
 //   Hooked*  the same files with INTEGRATION.md's five construction-site edits, i.e. the HIP library
 //            behind the reference's loops (one image per SIFT call, one pair per RANSAC call);
 //   Batched* the same files with INTEGRATION.md's batched hooks: calc_feature() is ONE op_sift_batch, the
-//            matcher object runs the whole task list through ONE op_match_pairs + ONE op_ransac_pairs --
+//            matcher object runs the whole task list through ONE op_match_pairs + ONE op_ransac_pairs, and
+//            (hook 6, host-only) estimate_camera() goes through libpano_host.so instead of the reference's
+//            CameraEstimator --
 // and run on the same image files in one process.  Compared: the "Final Image Size" of
 // stitcher_image.cc:124 (canvas dimensions) and every pixel of the panorama (<= 1e-4, north_star).
 //   ref_stitch_test <cylinder|camera|camera_ordered|trans> <seed> <multiband> img0.png img1.png ...
@@ -135,6 +137,15 @@ int main(int argc, char** argv) {
 	Mat32f got2 = cyl ? BatchedCylinderStitcher(files).build() : BatchedStitcher(files).build();
 	const double t_batch = now() - t0;
 	compare("batched", got2);
+	// Hook 6: the batched variant estimates the cameras with libpano_host.so (HostCameraEstimator, host/pano_camera.hh), the hooked
+	// one with the reference's own CameraEstimator / IncrementalBundleAdjuster (over the Eigen stand-in: parity unpinned at Eigen).
+	// Same match table in, so the same cameras must come out, digit for digit -- i.e. the two panoramas are bit-identical.
+	if (!timing && !cyl && mode != "trans") {
+		const bool same = got.rows() == got2.rows() && got.cols() == got2.cols() &&
+			memcmp(got.ptr(), got2.ptr(), sizeof(float) * 3 * (size_t)got.rows() * got.cols()) == 0;
+		printf("HOST_ESTIMATOR cameras of libpano_host.so == cameras of the reference's CameraEstimator (panoramas bit-identical): %s\n", same ? "yes" : "NO");
+		if (!same) { printf("FAIL: the host camera estimation hook changed the panorama\n"); ++fail; }
+	}
 	printf("DROPIN_MS {\"images\": %zu, \"mode\": \"%s\", \"cpu_threads\": %d, \"reference_cpu_build_ms\": %.1f, \"five_hooks_build_ms\": %.1f, \"batched_hooks_build_ms\": %.1f}\n",
 			files.size(), mode.c_str(), timing ? omp_get_num_procs() : 1, t_cpu, t_hook, t_batch);
 	printf(fail ? "STITCH DROPIN FAILED\n" : "STITCH DROPIN OK\n");
