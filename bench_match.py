@@ -201,7 +201,7 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
     torch.cuda.synchronize()
     log(f"strong {kind}: {len(ids)} local of {n} images generated in {time.perf_counter() - t0:.1f} s")
     eng = HipEngine(ctx, cfg, dev)
-    job = ShardedJob(eng, n, dev)
+    job = ShardedJob(eng, n, dev, overlap=True)        # N > 1: the pairs of two own images are matched while the exchange is in flight
     shapes = [(W, H)] * n
     call = hip.SiftCall(ctx, cfg, inputs) if inputs else None
     sift_in = (lambda: call()) if call is not None else []
@@ -221,8 +221,7 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
         if timed:
             prof = {kk: v[0] for kk, v in ctx.profile().items()}
             ctx.set_profiling(False)
-        seeds = job.seeds(1)
-        ok, inl = lap("ransac", lambda: eng.ransac_summary(job.tab, job.mh, job.my_pairs, shapes, seeds))
+        ok, inl = lap("ransac", lambda: job.ransac_summary(shapes, 1))
         if dist is not None:
             job.rres = None
             lap("result gather", job.gather)
@@ -238,10 +237,18 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
     names = list(ph)
     tm, sm = _reduce(dist, dev, [ph[x] for x in names] + [wall], [float(k), float(len(mine)), float(nm), float(ok), float(inl), flops])
     phm = dict(zip(names, tm[:-1]))
+    # every rank's own phase times (the maxima above decide the job; the spread says where a rank waits for another)
+    per_rank = None
+    if dist is not None:
+        mine_t = torch.tensor([ph[x] for x in names], dtype=torch.float64, device=dev)
+        allt = torch.empty(world * len(names), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine_t)
+        per_rank = [{x: round(float(v), 4) for x, v in zip(names, row)} for row in allt.view(world, len(names)).cpu()]
     res = {"workload": f"{what}; ONE job dealt round-robin over {world} GPU(s); inputs resident in HBM", "scaling": "strong",
            "images": n, "image": [H, W], "n_gpus": world, "descriptors": int(sm[0]), "keypoints_per_image": sm[0] / n,
            "image_pairs": int(sm[1]), "matches": int(sm[2]), "accepted_pairs": int(sm[3]), "inliers": int(sm[4]),
-           "phase_ms": {x: round(v, 4) for x, v in phm.items()}, "job_wall_ms": tm[-1],
+           "phase_ms": {x: round(v, 4) for x, v in phm.items()}, "per_rank_phase_ms": per_rank, "job_wall_ms": tm[-1],
+           "own_pairs_matched_during_exchange": len(job.local_sel),
            "keypoints_per_s": sm[0] / (phm["sift"] * 1e-3), "image_pairs_per_s": sm[1] / (phm["match"] * 1e-3),
            "matches_per_s": sm[2] / (phm["match"] * 1e-3), "ransac_image_pairs_per_s": sm[1] / (phm["ransac"] * 1e-3),
            "match_stage_ms": {x: round(v, 4) for x, v in prof.items() if x.startswith("matcher")},

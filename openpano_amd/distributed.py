@@ -79,16 +79,31 @@ def all_pairs(n: int):
     return [(i, j) for i in range(n) for j in range(i + 1, n)]
 
 
-def partition_pairs(pairs, rank: int, world: int, counts=None):
+def partition_pairs(pairs, rank: int, world: int, counts=None, blocks=None):
     """Deal pairs to ranks.  With ``counts`` the deal is balanced by K_i*K_j (longest first,
-    greedy); without, plain round-robin.  Deterministic and identical on every rank."""
+    greedy); without, plain round-robin.  Deterministic and identical on every rank.
+    ``blocks`` (image ids owned by every rank): a pair whose two images one rank owns goes to that rank first --
+    it can be matched while the feature exchange is still in flight -- and the rest is dealt on top of that load."""
     if counts is None:
         return pairs[rank::world]
     cost = [counts[i] * counts[j] for i, j in pairs]
-    order = sorted(range(len(pairs)), key=lambda k: (-cost[k], k))
     load = [0] * world
     mine = []
-    for k in order:
+    rest = range(len(pairs))
+    if blocks is not None:
+        owner = {}
+        for r, b in enumerate(blocks):
+            for g in b:
+                owner[g] = r
+        rest = []
+        for k, (i, j) in enumerate(pairs):
+            if owner.get(i, -1) == owner.get(j, -2):
+                load[owner[i]] += cost[k]
+                if owner[i] == rank:
+                    mine.append(pairs[k])
+            else:
+                rest.append(k)
+    for k in sorted(rest, key=lambda k: (-cost[k], k)):
         r = min(range(world), key=lambda q: (load[q], q))
         load[r] += cost[k]
         if r == rank:
@@ -105,12 +120,14 @@ def shard_images(n: int, rank: int, world: int):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def allgatherv_features(local_desc: torch.Tensor, local_coor: torch.Tensor, local_counts, n: int, group=None):
+def allgatherv_features(local_desc: torch.Tensor, local_coor: torch.Tensor, local_counts, n: int, group=None, wait=True):
     """The exchange step.  local_desc (K, 128) float32 / local_coor (K, 2) float64: this rank's images (the block
     ``shard_images(n, rank, world)``) back to back on its device.  Returns (desc, coor, counts) of ALL n images in
     global image order, identical on every rank: a header collective (per-image counts), then the slices are
     sent / received in place with one grouped batch of point-to-point operations -- ncclGroupStart/End under the
-    nccl backend, i.e. every pair of GPUs exchanges its two slices over its own xGMI link concurrently."""
+    nccl backend, i.e. every pair of GPUs exchanges its two slices over its own xGMI link concurrently.
+    ``wait=False`` returns (desc, coor, counts, pending works) right after posting: the own slice of the table is
+    already in place, the peers' slices are valid once every work has been waited for."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = local_desc.device
@@ -145,9 +162,11 @@ def allgatherv_features(local_desc: torch.Tensor, local_coor: torch.Tensor, loca
         if hi[src] > lo[src]:
             ops.append(dist.P2POp(dist.irecv, gdesc[lo[src]: hi[src]], src, group))
             ops.append(dist.P2POp(dist.irecv, gcoor[lo[src]: hi[src]], src, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:                                         # the caller overlaps work on what it already owns and waits itself
+        return gdesc, gcoor, counts, works
+    for w in works:
+        w.wait()
     return gdesc, gcoor, counts
 
 
@@ -263,9 +282,14 @@ class ShardedJob:
       gather()            -> {(gi, gj): (matches, ransac vector)} of the whole job on every rank
     Image ids are GLOBAL (0..n-1); rank r owns ``shard_images(n, r, world)``; the exchanged table is
     in global order and per-pair RANSAC seeds derive from the ids, so every result is independent of
-    the world size (tests/test_distributed_cpu.py compares world 2 with world 1)."""
+    the world size (tests/test_distributed_cpu.py compares world 2 and 3 with world 1).
 
-    def __init__(self, engine, n_images: int, device, group=None):
+    ``overlap=True``: the exchange is posted and NOT waited for; the pairs whose two images this rank owns (they are dealt
+    to it first, ``partition_pairs(blocks=...)``) are matched on its own features while the slices of the other ranks
+    travel, and only then the exchange is waited for -- ``exchange()`` returns with the local pairs already matched,
+    ``match()`` adds the rest.  Same pair list per job, same results per pair."""
+
+    def __init__(self, engine, n_images: int, device, group=None, overlap=False):
         self.e = engine
         self.n = n_images
         self.device = device
@@ -274,16 +298,15 @@ class ShardedJob:
         self.rank = dist.get_rank(group) if self.dist else 0
         self.world = dist.get_world_size(group) if self.dist else 1
         self.local_ids = shard_images(n_images, self.rank, self.world)
+        self.overlap = bool(overlap)
         self.tab = None; self.mh = None
+        self.local_tab = None; self.local_mh = None; self.local_lists = None
 
     def sift(self, local_images):
         assert callable(local_images) or len(local_images) == len(self.local_ids)
         # a single-rank table ADOPTS the engine's feature buffers, which the next sift() frees: results of the previous
         # generation go first, nothing may match against memory that is back in the pool
-        if self.mh is not None:
-            self.e.free(self.mh); self.mh = None
-        if self.tab is not None:
-            self.e.free(self.tab); self.tab = None
+        self._free_results()
         self.desc, self.coor, self.counts = self.e.sift(local_images)
         return sum(self.counts)
 
@@ -296,31 +319,63 @@ class ShardedJob:
         self._adopted = feats
         return sum(self.counts)
 
+    def _free_results(self):
+        for name in ("mh", "local_mh", "tab", "local_tab"):
+            obj = getattr(self, name, None)
+            if obj is not None:
+                self.e.free(obj); setattr(self, name, None)
+        self.local_lists = None
+
     def exchange(self):
         # the previous table goes first: its buffers are what the allocator hands out again for the new one (a second
         # generation of a 265 MB table costs two device allocations of several milliseconds each)
-        if self.tab is not None:
-            self.e.free(self.tab); self.tab = None
+        self._free_results()
         self._keep = None
+        works = []
         if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the header collective really runs
             # slices arrive in place, in GLOBAL image order: pair (i, j), its match list and its RANSAC draw
             # sequence are those of the single-rank job whatever the world size
-            gdesc, gcoor, gcounts = allgatherv_features(self.desc, self.coor, self.counts, self.n, self.group)
+            if self.overlap:
+                gdesc, gcoor, gcounts, works = allgatherv_features(self.desc, self.coor, self.counts, self.n, self.group, wait=False)
+            else:
+                gdesc, gcoor, gcounts = allgatherv_features(self.desc, self.coor, self.counts, self.n, self.group)
         else:
             gdesc, gcoor, gcounts = self.desc, self.coor, self.counts
         self._keep = (gdesc, gcoor)
-        self.tab = self.e.table(gdesc, gcoor, gcounts)
         self.gcounts = gcounts
-        self.my_pairs = partition_pairs(all_pairs(self.n), self.rank, self.world, gcounts if self.world > 1 else None)
+        blocks = [shard_images(self.n, r, self.world) for r in range(self.world)] if self.overlap else None
+        self.my_pairs = partition_pairs(all_pairs(self.n), self.rank, self.world, gcounts if self.world > 1 else None, blocks if self.world > 1 else None)
+        # pairs of two own images, in local indices: matched NOW, on the features this rank made, while the others' slices travel
+        first = self.local_ids[0] if self.local_ids else 0
+        own = set(self.local_ids)
+        self.local_sel = [k for k, (i, j) in enumerate(self.my_pairs) if i in own and j in own] if (self.overlap and self.world > 1) else []
+        if self.local_sel:
+            self.local_tab = self.e.table(self.desc, self.coor, self.counts)
+            self.local_pairs = [(self.my_pairs[k][0] - first, self.my_pairs[k][1] - first) for k in self.local_sel]
+            self.local_mh, self.local_lists = self.e.match(self.local_tab, self.local_pairs)
+        for w in works:
+            w.wait()
+        self.tab = self.e.table(gdesc, gcoor, gcounts)
         return sum(gcounts)
+
+    def _rest(self):
+        taken = set(self.local_sel)
+        return [k for k in range(len(self.my_pairs)) if k not in taken]
 
     def match(self, keep=True):
         if self.mh is not None:
             self.e.free(self.mh); self.mh = None
+        rest = self._rest()
+        rest_pairs = [self.my_pairs[k] for k in rest]
         if not keep:
-            self.e.match_only(self.tab, self.my_pairs)
+            self.e.match_only(self.tab, rest_pairs)
             return None
-        self.mh, self.lists = self.e.match(self.tab, self.my_pairs)
+        self.mh, rest_lists = self.e.match(self.tab, rest_pairs)
+        self.lists = [None] * len(self.my_pairs)
+        for k, m in zip(rest, rest_lists):
+            self.lists[k] = m
+        for k, m in zip(self.local_sel, self.local_lists or []):
+            self.lists[k] = m
         return sum(len(m) for m in self.lists)
 
     def seeds(self, base_seed):
@@ -328,8 +383,33 @@ class ShardedJob:
 
     def ransac(self, shapes_wh, base_seed=1):
         """shapes_wh: (w, h) per image id"""
-        self.rres = self.e.ransac(self.tab, self.mh, self.lists, self.my_pairs, shapes_wh, self.seeds(base_seed))
+        seeds = self.seeds(base_seed)
+        rest = self._rest()
+        out = [None] * len(self.my_pairs)
+        if rest:
+            rr = self.e.ransac(self.tab, self.mh, [self.lists[k] for k in rest], [self.my_pairs[k] for k in rest], shapes_wh, [seeds[k] for k in rest])
+            for k, r in zip(rest, rr):
+                out[k] = r
+        if self.local_sel:
+            lshapes = [shapes_wh[g] for g in self.local_ids]
+            rr = self.e.ransac(self.local_tab, self.local_mh, self.local_lists, self.local_pairs, lshapes, [seeds[k] for k in self.local_sel])
+            for k, r in zip(self.local_sel, rr):
+                out[k] = r
+        self.rres = out
         return sum(1 for r in self.rres if r["ok"])
+
+    def ransac_summary(self, shapes_wh, base_seed=1):
+        """RANSAC over this rank's pairs without unpacking every pair into Python (HipEngine) -> (accepted pairs, inliers)"""
+        seeds = self.seeds(base_seed)
+        rest = self._rest()
+        ok = inl = 0
+        if rest:
+            a, b = self.e.ransac_summary(self.tab, self.mh, [self.my_pairs[k] for k in rest], shapes_wh, [seeds[k] for k in rest])
+            ok += a; inl += b
+        if self.local_sel:
+            a, b = self.e.ransac_summary(self.local_tab, self.local_mh, self.local_pairs, [shapes_wh[g] for g in self.local_ids], [seeds[k] for k in self.local_sel])
+            ok += a; inl += b
+        return ok, inl
 
     def gather(self):
         """-> {(i, j): (matches (M,2) <idx in i, idx in j>, ransac vector | None)}, i < j, whole job"""
@@ -340,7 +420,4 @@ class ShardedJob:
         return {p: (m, extras[k] if extras else None) for k, (p, m) in enumerate(zip(self.my_pairs, self.lists))}
 
     def close(self):
-        if self.mh is not None:
-            self.e.free(self.mh); self.mh = None
-        if self.tab is not None:
-            self.e.free(self.tab); self.tab = None
+        self._free_results()

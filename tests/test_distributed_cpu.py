@@ -104,11 +104,11 @@ def _job_views():
     return [synth.cut_view(world, 20 + 6 * k, 20 + 110 * k, 200, 280, 70 + k) for k in range(5)]
 
 
-def _run_job(group_world, nviews=5):
+def _run_job(group_world, nviews=5, overlap=False):
     from openpano_amd.config import PanoConfig
     from openpano_amd.distributed import ShardedJob
     views = _job_views()[:nviews]
-    job = ShardedJob(OracleEngine(PanoConfig()), len(views), torch.device("cpu"))
+    job = ShardedJob(OracleEngine(PanoConfig()), len(views), torch.device("cpu"), overlap=overlap)
     assert job.world == group_world
     k_local = job.sift([views[g] for g in job.local_ids])
     k_total = job.exchange()
@@ -119,25 +119,27 @@ def _run_job(group_world, nviews=5):
     return k_local, k_total, job.gcounts, job.my_pairs, {k: (m.tolist(), ex.tolist()) for k, (m, ex) in res.items()}
 
 
-def _job_worker(rank, world, port, q, nviews=5):
+def _job_worker(rank, world, port, q, nviews=5, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    q.put((rank,) + _run_job(world, nviews))
+    q.put((rank,) + _run_job(world, nviews, overlap))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["exchange_then_match", "own_pairs_during_exchange"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_job_equals_single_rank(world):
+def test_sharded_job_equals_single_rank(world, overlap):
     """world 2: the even deal; world 3: 5 images over 3 ranks (2 + 2 + 1) and 10 pairs (ragged shards, a rank
-    with a single image) -- every rank must end with the single-rank job's results"""
+    with a single image) -- every rank must end with the single-rank job's results.  overlap: the pairs of two own
+    images are matched (on the rank's own features, local indices) before the exchange is waited for."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     single = _run_job(1)                     # no process group: the world-1 path of ShardedJob
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q, 5, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -151,6 +153,11 @@ def test_sharded_job_equals_single_rank(world):
     allp = [p for r in res for p in r[4]]
     assert sorted(allp) == pairs1 and len(set(allp)) == len(allp)         # a partition of the pair list
     assert all(len(r[4]) > 0 for r in res)
+    if overlap:                                           # every pair of two images of one rank's block is that rank's
+        from openpano_amd.distributed import shard_images
+        for r in res:
+            blk = set(shard_images(5, r[0], world))
+            assert all(p in r[4] for p in pairs1 if p[0] in blk and p[1] in blk)
     oa = res[0][5]
     assert all(r[5] == oa for r in res)                   # every rank holds the whole job after the gather
     assert sorted(oa) == sorted(out1)
