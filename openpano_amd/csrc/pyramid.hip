@@ -45,9 +45,18 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
 constexpr int WT = 64, WR = 16;               // working-image tile
 constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 
-// one source tap: fp32 as is, or a decoder byte converted like read_img (lib/imgio.cc:54-56,75-77)
-__device__ __forceinline__ float src_tap(const float* s, long long i, const float*) { return s[i]; }
-__device__ __forceinline__ float src_tap(const unsigned char* s, long long i, const float* lut) { return lut[s[i]]; }
+// six consecutive source elements from i (element-aligned only) -- fp32 as they are: one 16-byte and one 8-byte load; or
+// decoder bytes converted like read_img (lib/imgio.cc:54-56,75-77)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void src_run6(const float* s, long long i, const float*, float (&t)[6]) {
+	const f32x4_a4 a = *(const f32x4_a4*)(s + i); const f32x2_a4 b = *(const f32x2_a4*)(s + i + 4);
+	t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y;
+}
+__device__ __forceinline__ void src_run6(const unsigned char* s, long long i, const float* lut, float (&t)[6]) {
+#pragma unroll
+	for (int k = 0; k < 6; ++k) t[k] = lut[s[i + k]];
+}
 
 // s / 3.f (lib/imgproc.cc:245) as (float)((double)s * (1.0 / 3.0)): the double product is within 2^-52 of s / 3, and s / 3
 // is never that close to a rounding boundary of fp32 (3 * midpoint is an odd 26..27-bit integer multiple of the grid, no fp32
@@ -66,13 +75,21 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 	__shared__ int s_ri[TR], s_ci[TC];
 	__shared__ float s_rw[TR], s_cw[TC];
 	__shared__ long long s_ro[TR];            // working tile: element offset of the source row
-	const int img = blockIdx.z;
-	const int tx0 = blockIdx.x * WT, ty0 = blockIdx.y * WR;
+	// Workgroup b runs on XCD b % 8 (observed; a speed assumption only), and neighbouring tiles read the same source
+	// rows / columns at their seams: every XCD takes a CONTIGUOUS eighth of the row-major tile order, so a seam's second
+	// reader finds the lines in its own L2 instead of fetching them again through another one
+	const unsigned ntx = (unsigned)(p.ww + WT - 1) / WT, nty = (unsigned)(p.wh + WR - 1) / WR;
+	const unsigned ntile = ntx * nty * (unsigned)p.n, per = (ntile + 7u) >> 3;
+	const unsigned lin = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	if (lin >= ntile) return;
+	const int img = (int)(lin / (ntx * nty));
+	const unsigned trem = lin - (unsigned)img * (ntx * nty);
+	const int tx0 = (int)(trem % ntx) * WT, ty0 = (int)(trem / ntx) * WR;
 	const int tid = threadIdx.x;
 	const SrcT* src = (const SrcT*)p.srcs[img];
 	// the step's counters (raw / refined / oriented per image, total) start at zero: cleared here, by the first kernel
 	// of the step, instead of by a fill launch of their own (nothing reads or adds to them before this kernel has ended)
-	if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.zero)
+	if (blockIdx.x == 0 && p.zero)
 		for (int i = tid; i < p.zero_n; i += 256) p.zero[i] = 0;
 	if (sizeof(SrcT) == 1) s_lut[tid] = (float)((double)(float)tid / 255.0);      // (float)byte / 255.0: float -> double, IEEE division, round to float
 	// working-image tile: lib/imgproc.cc:22-80 on the source
@@ -98,9 +115,15 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 				const float rx = s_rw[r], ry = s_cw[c];
 				const float irx = 1.0f - rx, iry = 1.0f - ry;
 				const long long i0 = s_ro[r] + sy3, i1 = i0 + (long long)p.sw * 3;
-				v0 = bilerp(src_tap(src, i0, s_lut), src_tap(src, i0 + 3, s_lut), src_tap(src, i1, s_lut), src_tap(src, i1 + 3, s_lut), rx, irx, ry, iry);
-				v1 = bilerp(src_tap(src, i0 + 1, s_lut), src_tap(src, i0 + 4, s_lut), src_tap(src, i1 + 1, s_lut), src_tap(src, i1 + 4, s_lut), rx, irx, ry, iry);
-				v2 = bilerp(src_tap(src, i0 + 2, s_lut), src_tap(src, i0 + 5, s_lut), src_tap(src, i1 + 2, s_lut), src_tap(src, i1 + 5, s_lut), rx, irx, ry, iry);
+				// the 2 x 2 taps of one working pixel are two runs of 6 consecutive source elements (two RGB pixels of row sx and of
+				// row sx + 1): fetched as such.  Neighbouring lanes' runs are 3-6 elements apart, so a wavefront's 16-byte load
+				// covers a contiguous kilobyte -- as 12 separate dword loads per pixel the same lines went through the address
+				// path twelve times, and the kernel waited on it
+				float t0[6], t1[6];
+				src_run6(src, i0, s_lut, t0); src_run6(src, i1, s_lut, t1);
+				v0 = bilerp(t0[0], t0[3], t1[0], t1[3], rx, irx, ry, iry);
+				v1 = bilerp(t0[1], t0[4], t1[1], t1[4], rx, irx, ry, iry);
+				v2 = bilerp(t0[2], t0[5], t1[2], t1[5], rx, irx, ry, iry);
 				if (write_work && r < WR && c < WT) {
 					float* dst = p.work + (((long long)img * p.wh + ty0 + r) * p.ww + tx0 + c) * 3;
 					dst[0] = v0; dst[1] = v1; dst[2] = v2;
@@ -804,7 +827,8 @@ size_t pyramid_lds_bytes(int halo) {
 }
 
 hipError_t launch_grey_octaves(const SiftPlan& p, bool write_work, hipStream_t st) {
-	dim3 grid((p.ww + WT - 1) / WT, (p.wh + WR - 1) / WR, p.n);
+	const unsigned ntile = (unsigned)((p.ww + WT - 1) / WT) * (unsigned)((p.wh + WR - 1) / WR) * (unsigned)p.n;
+	dim3 grid(((ntile + 7u) >> 3) << 3);              // eight per-XCD queues of equal length (the kernel drops the padding)
 	if (p.src_u8) hipLaunchKernelGGL(k_grey_octaves<unsigned char>, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
 	else hipLaunchKernelGGL(k_grey_octaves<float>, grid, dim3(256), 0, st, p, write_work ? 1 : 0);
 	return hipGetLastError();
