@@ -49,13 +49,17 @@ constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 // decoder bytes converted like read_img (lib/imgio.cc:54-56,75-77)
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+// (the sources arrive through a pointer table, i.e. as generic pointers: they are device memory, and said to be -- a flat
+// load counts on the LDS counter too, and the LDS reads of the coordinate tables would wait for every source load before them)
+#define OP_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ void src_run6(const float* s, long long i, const float*, float (&t)[6]) {
-	const f32x4_a4 a = *(const f32x4_a4*)(s + i); const f32x2_a4 b = *(const f32x2_a4*)(s + i + 4);
+	const OP_GLOBAL float* g = (const OP_GLOBAL float*)s + i;
+	const f32x4_a4 a = *(const OP_GLOBAL f32x4_a4*)g; const f32x2_a4 b = *(const OP_GLOBAL f32x2_a4*)(g + 4);
 	t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y;
 }
 __device__ __forceinline__ void src_run6(const unsigned char* s, long long i, const float* lut, float (&t)[6]) {
 #pragma unroll
-	for (int k = 0; k < 6; ++k) t[k] = lut[s[i + k]];
+	for (int k = 0; k < 6; ++k) t[k] = lut[((const OP_GLOBAL unsigned char*)s)[i + k]];
 }
 
 // s / 3.f (lib/imgproc.cc:245) as (float)((double)s * (1.0 / 3.0)): the double product is within 2^-52 of s / 3, and s / 3
@@ -107,23 +111,35 @@ __global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work
 			s_ci[c] = sy < 0 ? -1 : sy * 3; s_cw[c] = ry;
 		}
 		__syncthreads();
-		for (int e = tid; e < (WR + 1) * (WT + 1); e += 256) {
+		// Every thread owns NE elements of the (WR + 1) x (WT + 1) tile.  All of their source runs are requested first -- the
+		// 2 x 2 taps of one working pixel are two runs of 6 consecutive source elements (two RGB pixels of row sx and of
+		// row sx + 1), fetched as one 16-byte and one 8-byte load each; neighbouring lanes' runs are 3-6 elements apart, so a
+		// wavefront's load covers a contiguous kilobyte -- and only then interpolated: 20 loads in flight per thread instead
+		// of 4 (the kernel streams the source once and does little else; what it needs is outstanding bytes)
+		constexpr int NE = ((WR + 1) * (WT + 1) + 255) / 256;
+		float t0[NE][6], t1[NE][6];
+		bool live[NE];
+#pragma unroll
+		for (int k = 0; k < NE; ++k) {                   // no branch around the loads: an element without taps reads the image's first run and drops it
+			const int e = tid + 256 * k < (WR + 1) * (WT + 1) ? tid + 256 * k : 0;
 			const int r = e / (WT + 1), c = e % (WT + 1);
 			const int sx = s_ri[r], sy3 = s_ci[c];
+			live[k] = sx >= 0 && sy3 >= 0;
+			const long long i0 = live[k] ? s_ro[r] + sy3 : 0, i1 = i0 + (long long)p.sw * 3;
+			src_run6(src, i0, s_lut, t0[k]); src_run6(src, i1, s_lut, t1[k]);
+		}
+#pragma unroll
+		for (int k = 0; k < NE; ++k) {
+			const int e = tid + 256 * k;
+			if (e >= (WR + 1) * (WT + 1)) break;
+			const int r = e / (WT + 1), c = e % (WT + 1);
 			float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-			if (sx >= 0 && sy3 >= 0) {
+			if (live[k]) {
 				const float rx = s_rw[r], ry = s_cw[c];
 				const float irx = 1.0f - rx, iry = 1.0f - ry;
-				const long long i0 = s_ro[r] + sy3, i1 = i0 + (long long)p.sw * 3;
-				// the 2 x 2 taps of one working pixel are two runs of 6 consecutive source elements (two RGB pixels of row sx and of
-				// row sx + 1): fetched as such.  Neighbouring lanes' runs are 3-6 elements apart, so a wavefront's 16-byte load
-				// covers a contiguous kilobyte -- as 12 separate dword loads per pixel the same lines went through the address
-				// path twelve times, and the kernel waited on it
-				float t0[6], t1[6];
-				src_run6(src, i0, s_lut, t0); src_run6(src, i1, s_lut, t1);
-				v0 = bilerp(t0[0], t0[3], t1[0], t1[3], rx, irx, ry, iry);
-				v1 = bilerp(t0[1], t0[4], t1[1], t1[4], rx, irx, ry, iry);
-				v2 = bilerp(t0[2], t0[5], t1[2], t1[5], rx, irx, ry, iry);
+				v0 = bilerp(t0[k][0], t0[k][3], t1[k][0], t1[k][3], rx, irx, ry, iry);
+				v1 = bilerp(t0[k][1], t0[k][4], t1[k][1], t1[k][4], rx, irx, ry, iry);
+				v2 = bilerp(t0[k][2], t0[k][5], t1[k][2], t1[k][5], rx, irx, ry, iry);
 				if (write_work && r < WR && c < WT) {
 					float* dst = p.work + (((long long)img * p.wh + ty0 + r) * p.ww + tx0 + c) * 3;
 					dst[0] = v0; dst[1] = v1; dst[2] = v2;
