@@ -94,35 +94,72 @@ __device__ __forceinline__ bool interpolate(const float* __restrict__ img, int r
 	return true;
 }
 
+// The canvas-pixel kernels below walk "every image whose ROI holds this pixel, in index order".  Testing all n ROIs per
+// pixel made them scalar-bound (38 images: 38 descriptor loads and 152 compares per pixel for the two or three that
+// cover it): a workgroup -- a 64 x 4 pixel tile -- first marks the images whose ROI meets its TILE (one image per lane,
+// one ballot per 64 images), then every pixel walks only those, with the exact per-pixel test of the reference.
+constexpr int COVER_WORDS = 64;          // images per round of the walk: 64 x 64
+__device__ __forceinline__ void tile_cover(const BlendImg* __restrict__ imgs, int k0, int n, int i0, int j0, int excl, unsigned long long* s_cover) {
+	const int k1 = n - k0 < COVER_WORDS * 64 ? n : k0 + COVER_WORDS * 64;
+	__syncthreads();                                    // the previous round's list is no longer read
+	for (int k = k0 + (int)threadIdx.x; k < ((k1 - k0 + 63) & ~63) + k0; k += 256) {
+		bool hit = false;
+		if (k < k1) {
+			const BlendImg& im = imgs[k];
+			hit = im.x0 <= j0 + 63 && im.x1 - excl >= j0 && im.y0 <= i0 + 3 && im.y1 - excl >= i0;
+		}
+		const unsigned long long b = __ballot(hit);
+		if ((threadIdx.x & 63) == 0) s_cover[(k - k0) >> 6] = b;
+	}
+	__syncthreads();
+}
+// visit(k) for every marked image of the round starting at k0, ascending; the list is wave-uniform (scalar loop control)
+template <typename F>
+__device__ __forceinline__ void walk_cover(const unsigned long long* s_cover, int k0, int n, F&& visit) {
+	const int words = ((n - k0 < COVER_WORDS * 64 ? n - k0 : COVER_WORDS * 64) + 63) >> 6;
+	for (int wd = 0; wd < words; ++wd) {
+		const unsigned long long mw = s_cover[wd];
+		unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mw), hi = __builtin_amdgcn_readfirstlane((unsigned)(mw >> 32));
+		while (lo) { const int b = __builtin_ctz(lo); lo &= lo - 1; visit(k0 + wd * 64 + b); }
+		while (hi) { const int b = __builtin_ctz(hi); hi &= hi - 1; visit(k0 + wd * 64 + 32 + b); }
+	}
+}
+
 // ---- LinearBlender::run (blender.cc:24-96): thread per canvas pixel, images in index order ----
 __global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, const BlendImg* __restrict__ imgs, int n,
 		float* __restrict__ out, int H, int W, int ordered_input, int lazy) {
+	__shared__ unsigned long long s_cover[COVER_WORDS];
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (i >= H || j >= W) return;
+	const bool live = i < H && j < W;
 	const double cx = (double)j * g.resx + g.minx;
 	const double cy = (double)i * g.resy + g.miny;
 	double hx, hy, hz;
 	proj2homo(g.method, cx, cy, hx, hy, hz);
 	float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
-	for (int k = 0; k < n; ++k) {
-		const BlendImg& im = imgs[k];
-		// non-lazy: Range::contain, inclusive (blender.cc:84); lazy: loops exclude max (blender.cc:49-51)
-		const bool in = lazy ? (i >= im.y0 && i < im.y1 && j >= im.x0 && j < im.x1)
-		                     : (i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1);
-		if (!in) continue;
-		double ox, oy;
-		space_to_image(im, hx, hy, hz, ox, oy);
-		if (ox < 0 || ox >= im.w || oy < 0 || oy >= im.h) continue;      // ImageToAdd::map_coor (blender.hh:39-44)
-		const float r = (float)oy, c = (float)ox;
-		float col[3];
-		if (!interpolate(im.data, im.mh, im.mw, r, c, col)) continue;
-		if (col[0] < 0) continue;
-		float w = (float)(0.5 - fabs((double)(c / (float)im.w) - 0.5));
-		if (!ordered_input) w = (float)((double)w * (0.5 - fabs((double)(r / (float)im.h) - 0.5)));
-		s0 += col[0] * w; s1 += col[1] * w; s2 += col[2] * w;
-		wsum += w;
+	for (int k0 = 0; k0 < n; k0 += COVER_WORDS * 64) {
+		tile_cover(imgs, k0, n, blockIdx.y * 4, blockIdx.x * 64, lazy ? 1 : 0, s_cover);
+		if (!live) continue;
+		walk_cover(s_cover, k0, n, [&](int k) {
+			const BlendImg& im = imgs[k];
+			// non-lazy: Range::contain, inclusive (blender.cc:84); lazy: loops exclude max (blender.cc:49-51)
+			const bool in = lazy ? (i >= im.y0 && i < im.y1 && j >= im.x0 && j < im.x1)
+			                     : (i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1);
+			if (!in) return;
+			double ox, oy;
+			space_to_image(im, hx, hy, hz, ox, oy);
+			if (ox < 0 || ox >= im.w || oy < 0 || oy >= im.h) return;      // ImageToAdd::map_coor (blender.hh:39-44)
+			const float r = (float)oy, c = (float)ox;
+			float col[3];
+			if (!interpolate(im.data, im.mh, im.mw, r, c, col)) return;
+			if (col[0] < 0) return;
+			float w = (float)(0.5 - fabs((double)(c / (float)im.w) - 0.5));
+			if (!ordered_input) w = (float)((double)w * (0.5 - fabs((double)(r / (float)im.h) - 0.5)));
+			s0 += col[0] * w; s1 += col[1] * w; s2 += col[2] * w;
+			wsum += w;
+		});
 	}
+	if (!live) return;
 	float* row = out + ((long long)i * W + j) * 3;
 	if (lazy) {
 		if (wsum != 0.f) { row[0] = s0 / wsum; row[1] = s1 / wsum; row[2] = s2 / wsum; }   // blender.cc:68-70
@@ -150,32 +187,37 @@ __global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, const Blend
 	// (blender.hh:19-27): an ROI's last column / row can lie ONE pixel outside the target.  The reference still builds
 	// that pixel of the image's level 0 (it feeds the blurs) but its weight-map walk never visits it, so it keeps its
 	// own weight; the grid therefore covers (H + 1) x (W + 1) and only pixels inside the target take part in the map.
-	if (i > H || j > W) return;
+	__shared__ unsigned long long s_cover[COVER_WORDS];
+	const bool live = !(i > H || j > W);
 	const bool inside = i < H && j < W;
 	const double cx = (double)j * g.resx + g.minx;
 	const double cy = (double)i * g.resy + g.miny;
 	double hx, hy, hz;
 	proj2homo(g.method, cx, cy, hx, hy, hz);
 	float mx = 0.f; long long maxe = -1;
-	for (int k = 0; k < n; ++k) {
-		const BlendImg& im = imgs[k];
-		if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) continue;
-		const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
-		double ox, oy;
-		space_to_image(im, hx, hy, hz, ox, oy);
-		float col[3];
-		bool ok = interpolate(im.data, im.mh, im.mw, (float)oy, (float)ox, col);
-		if (ok) { float mn = fminf(col[0], fminf(col[1], col[2])); if (mn < 0) ok = false; }
-		float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
-		if (ok) {
-			const double x = ox / (double)im.w - 0.5, y = oy / (double)im.h - 0.5;
-			const double v = (0.5 - fabs(x)) * (0.5 - fabs(y));
-			const float w = (float)((v > 0.0 ? v : 0.0) + 1e-6);
-			px = make_float4(col[0], col[1], col[2], inside ? 0.f : w);
-			if (w > mx) { mx = w; maxe = e; }                     // multiband.cc:133-137
-		}
-		cur[e] = px;
-		mask[e] = ok ? 0 : 1;
+	for (int k0 = 0; k0 < n; k0 += COVER_WORDS * 64) {
+		tile_cover(imgs, k0, n, blockIdx.y * 4, blockIdx.x * 64, 0, s_cover);
+		if (!live) continue;
+		walk_cover(s_cover, k0, n, [&](int k) {
+			const BlendImg& im = imgs[k];
+			if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) return;
+			const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
+			double ox, oy;
+			space_to_image(im, hx, hy, hz, ox, oy);
+			float col[3];
+			bool ok = interpolate(im.data, im.mh, im.mw, (float)oy, (float)ox, col);
+			if (ok) { float mn = fminf(col[0], fminf(col[1], col[2])); if (mn < 0) ok = false; }
+			float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (ok) {
+				const double x = ox / (double)im.w - 0.5, y = oy / (double)im.h - 0.5;
+				const double v = (0.5 - fabs(x)) * (0.5 - fabs(y));
+				const float w = (float)((v > 0.0 ? v : 0.0) + 1e-6);
+				px = make_float4(col[0], col[1], col[2], inside ? 0.f : w);
+				if (w > mx) { mx = w; maxe = e; }                     // multiband.cc:133-137
+			}
+			cur[e] = px;
+			mask[e] = ok ? 0 : 1;
+		});
 	}
 	if (!inside) return;
 	if (maxe >= 0) ((float*)&cur[maxe])[3] = 1.f;
@@ -358,31 +400,37 @@ __global__ void __launch_bounds__(256) k_mb_bands(const BlendImg* __restrict__ i
 		const unsigned char* __restrict__ mask, float* __restrict__ out, unsigned char* __restrict__ tmask, int H, int W) {
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (i >= H || j >= W) return;
+	__shared__ unsigned long long s_cover[COVER_WORDS];
+	const bool live = i < H && j < W;
 	float s0[NL], s1[NL], s2[NL], ws[NL];
 #pragma unroll
 	for (int l = 0; l < NL; ++l) { s0[l] = 0.f; s1[l] = 0.f; s2[l] = 0.f; ws[l] = 0.f; }
-	for (int k = 0; k < n; ++k) {
-		const BlendImg& im = imgs[k];
-		if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) continue;
-		const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
-		if (mask[e]) continue;
-		float4 lvl[NL];
+	for (int k0 = 0; k0 < n; k0 += COVER_WORDS * 64) {
+		tile_cover(imgs, k0, n, blockIdx.y * 4, blockIdx.x * 64, 0, s_cover);
+		if (!live) continue;
+		walk_cover(s_cover, k0, n, [&](int k) {
+			const BlendImg& im = imgs[k];
+			if (!(i >= im.y0 && i <= im.y1 && j >= im.x0 && j <= im.x1)) return;
+			const long long e = im.roi_off + (long long)(i - im.y0) * im.rw + (j - im.x0);
+			if (mask[e]) return;
+			float4 lvl[NL];
 #pragma unroll
-		for (int l = 0; l < NL; ++l) lvl[l] = P.lv[l][e];
+			for (int l = 0; l < NL; ++l) lvl[l] = P.lv[l][e];
 #pragma unroll
-		for (int l = 0; l < NL; ++l) {
-			const float4 cc = lvl[l];
-			if (cc.w <= 0) continue;
-			if (l < NL - 1) {
-				const float4 cn = lvl[l + 1];
-				s0[l] += (cc.x - cn.x) * cc.w; s1[l] += (cc.y - cn.y) * cc.w; s2[l] += (cc.z - cn.z) * cc.w;
-			} else {
-				s0[l] += cc.x * cc.w; s1[l] += cc.y * cc.w; s2[l] += cc.z * cc.w;
+			for (int l = 0; l < NL; ++l) {
+				const float4 cc = lvl[l];
+				if (cc.w <= 0) continue;
+				if (l < NL - 1) {
+					const float4 cn = lvl[l + 1];
+					s0[l] += (cc.x - cn.x) * cc.w; s1[l] += (cc.y - cn.y) * cc.w; s2[l] += (cc.z - cn.z) * cc.w;
+				} else {
+					s0[l] += cc.x * cc.w; s1[l] += cc.y * cc.w; s2[l] += cc.z * cc.w;
+				}
+				ws[l] += cc.w;
 			}
-			ws[l] += cc.w;
-		}
+		});
 	}
+	if (!live) return;
 	const long long pe = (long long)i * W + j;
 	float* p = out + pe * 3;
 	const bool seen0 = tmask[pe] != 0;
