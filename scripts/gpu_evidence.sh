@@ -1,13 +1,15 @@
 #!/bin/bash
-# Round-3 evidence pass for the CURRENT build of the library (everything lands under gpurun_out/<tag>_*; copy what is kept to profiles/):
+# Evidence pass for the CURRENT build of the library (everything lands under gpurun_out/<tag>_*; copy what is kept to profiles/):
 #   1 whole GPU suite                         -> <tag>_pytest.log
 #   2 default bench (parity + CPU baselines)  -> <tag>_bench.json
 #   3 rocprofv3 --kernel-trace --stats of a config-4 bench run (numpy-made inputs: no torch kernels in the table) -> <tag>_prof/
 #   4 the four PMC passes of scripts/gpu_pmc.sh (pmc json carries the library hash; bench.py replays traffic only for the same hash)
 #   5 one-rank RCCL run (OPENPANO_FORCE_DIST=1): the exchange / gather code on the nccl backend
-#   6 micro-benchmarks the matcher section of DESIGN.md quotes: mfma_power, mfma_valu_overlap, the sweep's phase trace
-# Usage: scripts/gpu_r03_evidence.sh <tag> [sections, default "1 2 3 4 5 6"]
-tag=${1:-r03}; what=${2:-"1 2 3 4 5 6"}
+#   6 micro-benchmarks DESIGN.md quotes: mfma_power, mfma_valu_overlap, lds_atomic_order, the sweep's phase trace (if that variant is built)
+#   7 the SIFT step on 38 / 19 / 10 / 5 of the config-4 images (one rank's share at N = 1 / 2 / 4 / 8)  -> <tag>_sift_shares.txt
+#   8 the whole config-5 job against the oracle, all 8128 pairs (OPENPANO_FULL_C5=1; minutes of host time) -> <tag>_config5_all_pairs.txt
+# Usage: scripts/gpu_evidence.sh <tag> [sections, default "1 2 3 4 5 6 7"]
+tag=${1:-r04}; what=${2:-"1 2 3 4 5 6 7"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 has() { [[ " $what " == *" $1 "* ]]; }
@@ -20,24 +22,33 @@ if has 2; then
   echo "[bench rc=$?]"; tail -4 gpurun_out/${tag}_bench.err
 fi
 if has 3; then
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o sift -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest \
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o sift -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest --no-configs \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err
   f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv && cut -c1-170 "$f" | head -22
 fi
 if has 4; then
-  bash scripts/gpu_pmc.sh ${tag} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest 2>&1 | tail -30
+  bash scripts/gpu_pmc.sh ${tag} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --no-ingest --no-configs 2>&1 | tail -30
 fi
 if has 5; then
-  ( OPENPANO_FORCE_DIST=1 timeout 600 python bench.py --steps 10 --no-cpu-baseline --no-e2e --no-blend --no-ingest ) > gpurun_out/${tag}_bench_forcedist.json 2> gpurun_out/${tag}_bench_forcedist.err
+  ( OPENPANO_FORCE_DIST=1 timeout 600 python bench.py --steps 10 --no-cpu-baseline --no-e2e --no-blend --no-ingest --no-configs ) > gpurun_out/${tag}_bench_forcedist.json 2> gpurun_out/${tag}_bench_forcedist.err
   echo "[forcedist rc=$?]"
 fi
 if has 6; then
-  for b in mfma_power mfma_valu_overlap; do
+  for b in mfma_power mfma_valu_overlap lds_atomic_order; do
     [ -x scripts/ubench/$b ] && ( echo "== scripts/ubench/$b"; timeout 120 scripts/ubench/$b ) > gpurun_out/${tag}_ubench_$b.txt 2>&1
     tail -8 gpurun_out/${tag}_ubench_$b.txt
   done
   [ -f openpano_amd/variants/libopenpano_hip_match9.so ] && ( OPENPANO_TRACE_LIB=match9 timeout 600 python scripts/match_trace.py ) > gpurun_out/${tag}_match_trace.txt 2>&1
   grep "^K=\|residents" gpurun_out/${tag}_match_trace.txt | cut -c1-400
+fi
+if has 7; then
+  ( echo "# scripts/sift_ab.py --steps 60 --images N: the SIFT step of one rank's share of BASELINE config 4 under strong scaling (N = 38 / 19 / 10 / 5 images = 1 / 2 / 4 / 8 ranks), one MI355X"
+    for n in 38 19 10 5; do echo "images $n"; timeout 200 python scripts/sift_ab.py --steps 60 --images $n 2>&1 | grep step; done ) > gpurun_out/${tag}_sift_shares.txt
+  cat gpurun_out/${tag}_sift_shares.txt
+fi
+if has 8; then
+  ( time OPENPANO_FULL_C5=1 timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k whole_match_job ) > gpurun_out/${tag}_config5_all_pairs.txt 2>&1
+  tail -6 gpurun_out/${tag}_config5_all_pairs.txt
 fi
 python - <<PY
 import json
