@@ -38,8 +38,8 @@ if has 6; then
     [ -x scripts/ubench/$b ] && ( echo "== scripts/ubench/$b"; timeout 120 scripts/ubench/$b ) > gpurun_out/${tag}_ubench_$b.txt 2>&1
     tail -8 gpurun_out/${tag}_ubench_$b.txt
   done
-  [ -f openpano_amd/variants/libopenpano_hip_match9.so ] && ( OPENPANO_TRACE_LIB=match9 timeout 600 python scripts/match_trace.py ) > gpurun_out/${tag}_match_trace.txt 2>&1
-  grep "^K=\|residents" gpurun_out/${tag}_match_trace.txt | cut -c1-400
+
+
 fi
 if has 7; then
   ( echo "# scripts/sift_ab.py --steps 60 --images N: the SIFT step of one rank's share of BASELINE config 4 under strong scaling (N = 38 / 19 / 10 / 5 images = 1 / 2 / 4 / 8 ranks), one MI355X"
