@@ -84,3 +84,59 @@ def test_stitch_demo_over_a_device_group(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(open(fout, "rb").read())
     assert len(outs[0]) > 1000 and outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_job_overlap_path_on_the_device(cfg, monkeypatch, world):
+    """openpano_amd.distributed.ShardedJob(overlap=True) with the PRODUCT engine (HipEngine), one emulated rank after the
+    other on the one device of the box: the exchange is replaced by the table the ranks' own SIFT calls add up to (the
+    collectives themselves run on gloo ranks in tests/test_distributed_cpu.py and on a one-rank RCCL group in bench.py),
+    everything else is the code a rank runs at N > 1 -- own-pairs-first deal, the pairs of two own images matched on a
+    table adopted over the rank's own SIFT output (local indices), the rest on the global table, RANSAC over both handles
+    with seeds from the global pair ids, ransac_summary -- and must reproduce the single-rank job pair for pair."""
+    import torch
+    from openpano_amd import hip, distributed as D
+    base = synth.make_world(77, 360, 1200, work_scale=1600.0 / (300 + 400), density=900.0)
+    imgs = [synth.cut_view(base, 20 + 4 * k, 20 + 110 * k, 300, 400, 70 + k) for k in range(7)]     # a sweep: neighbours overlap
+    n = len(imgs)
+    shapes = [(400, 300)] * n
+    dev = torch.device("cuda", 0)
+    ctx = hip.Context(0)
+    # the single-rank job
+    eng1 = D.HipEngine(ctx, cfg, dev)
+    job1 = D.ShardedJob(eng1, n, dev)
+    job1.sift(imgs); job1.exchange(); job1.match(); job1.ransac(shapes, base_seed=3)
+    want = {p: (m.copy(), r) for p, m, r in zip(job1.my_pairs, job1.lists, job1.rres)}
+    gdesc, gcoor, gcounts = job1.desc.clone(), job1.coor.clone(), list(job1.counts)
+    ok1, inl1 = job1.ransac_summary(shapes, 3)
+    job1.close()
+    seen = {}
+    tot_ok = tot_inl = 0
+    for rank in range(world):
+        eng = D.HipEngine(ctx, cfg, dev)
+        job = D.ShardedJob(eng, n, dev, overlap=True)
+        job.world, job.rank, job.dist = world, rank, True
+        job.local_ids = D.shard_images(n, rank, world)
+        monkeypatch.setattr(D, "allgatherv_features", lambda d, c, cnt, nn, group=None, wait=True: (gdesc, gcoor, gcounts, []) if not wait else (gdesc, gcoor, gcounts))
+        k_local = job.sift([imgs[g] for g in job.local_ids])
+        assert k_local == sum(gcounts[g] for g in job.local_ids)
+        job.exchange()
+        blk = set(job.local_ids)
+        own = [p for p in D.all_pairs(n) if p[0] in blk and p[1] in blk]
+        assert all(p in job.my_pairs for p in own) and len(job.local_sel) == len(own)
+        job.match(); job.ransac(shapes, base_seed=3)
+        for p, m, r in zip(job.my_pairs, job.lists, job.rres):
+            assert p not in seen
+            seen[p] = True
+            wm, wr = want[p]
+            assert np.array_equal(m, wm), (rank, p)
+            assert r["ok"] == wr["ok"] and r["best_hyp"] == wr["best_hyp"] and r["confidence"] == wr["confidence"], (rank, p)
+            assert np.array_equal(r["inliers"], wr["inliers"]) and np.array_equal(r["homo"], wr["homo"]), (rank, p)
+        a, b = job.ransac_summary(shapes, 3)
+        tot_ok += a; tot_inl += b
+        job.close()
+        if eng._feats is not None:
+            eng._feats.free(); eng._feats = None
+    assert sorted(seen) == D.all_pairs(n)
+    assert (tot_ok, tot_inl) == (ok1, inl1) and ok1 >= 3
+    ctx.close()
