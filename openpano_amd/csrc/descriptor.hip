@@ -207,9 +207,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 			x_rot = (float)((double)(fxx * cosort + fyy * sinort) * rd);
 		};
 
-		// phases 1b - 3 on one dense batch of queued survivors (window order preserved)
-		auto process_batch = [&](int n) {
-			const bool ok = lane < n;
+		// phases 1b - 3 on one batch of up to 64 window samples in window order (lanes with cand == false carry none)
+		auto process_batch = [&](bool cand, int xx, int yy) {
+			// the reference's window tests (sift.cc:113-126): inside the circle, both rotated coordinates inside the
+			// 4 x 4 bin square;  between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
+			float x_rot, y_rot;
+			rotate(xx, yy, x_rot, y_rot);
+			const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
+			const bool ok = cand && !((float)xx * (float)xx + (float)yy * (float)yy > fr2)
+				&& ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f;
 			int a0 = 0;                                        // byte offset of mask[(ybinf * 4 + xbinf) * 8 + hbinf % 8]
 			int a1 = 0;                                        // the same for (hbinf + 1) % 8
 			float vA[4], vB[4];                                // per touched cell: the values for orientation bins h0 and h0 + 1
@@ -217,12 +223,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 #pragma unroll
 			for (int u = 0; u < 4; ++u) { vA[u] = 0.f; vB[u] = 0.f; }
 			if (ok) {
-				const unsigned pk = S.q[(qhead + lane) & (QCAP - 1)];
-				const int xx = (int)(pk & 0xFFu) - 128, yy = (int)((pk >> 8) & 0xFFu) - 128;
-				float x_rot, y_rot;
-				rotate(xx, yy, x_rot, y_rot);
 				const int gi = (kpy + yy) * w + (kpx + xx);
-				const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
 				const float gdy = g_img[gi + w] - g_img[gi - w];
 				const float gdx = g_img[gi + 1] - g_img[gi - 1];
 				const float now_mag = opdev::hypotf_glibc(gdx, gdy);
@@ -336,47 +337,55 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 			}
 			S.mask[lane] = 0ULL; S.mask[lane + 64] = 0ULL;
 			WAVE_FENCE();
-			qhead = (qhead + n) & (QCAP - 1); qn -= n;
 		};
 
-		// phase 1a: candidates in the reference's order (xx outer, yy inner: sift.cc:110-113); the
-		// cheap tests run on all candidates, survivors are queued in order and handed to the expensive
-		// phases 64 at a time, so those always run with full wavefronts
+		// phase 1a: the window in the reference's order (xx outer, yy inner: sift.cc:110-113).  With column intervals
+		// nearly every candidate passes the window tests (1.02 candidates per kept sample), so 64 consecutive candidates
+		// ARE a batch.  The full-window walk keeps a third of its samples: there the cheap tests run first and the
+		// survivors are queued in order and handed on 64 at a time, so the expensive phases run with full wavefronts.
 		int qx = lane / side, qy = lane % side;          // full-window walk: sample e = i0 + lane  ->  (e / side, e % side)
 		int kbase = -1;                                  // listed columns started before this step, minus one
-		for (int i0 = 0; i0 < ncand; i0 += 64) {
-			bool ok = false;
+		for (int i0 = 0; i0 < ncand || qn > 0; i0 += 64) {
+			bool cand = i0 + lane < ncand, run = true;
 			int xx = 0, yy = 0;
-			int ord = 0;
 			if (cols) {
 				const unsigned long long sb = S.startbits[i0 >> 6];
-				ord = kbase + rank_below(sb) + (int)((unsigned)(sb >> lane) & 1u);
+				const int ord = kbase + rank_below(sb) + (int)((unsigned)(sb >> lane) & 1u);
 				kbase += __popcll(sb);
-			}
-			if (i0 + lane < ncand) {
-				if (cols) {
+				if (cand) {
 					const unsigned pk = S.colpk[ord];
 					xx = (int)(pk & 0xFFu) - radius; yy = (int)(signed char)(pk >> 8) + (i0 + lane - (int)(pk >> 16));
-				} else { xx = qx - radius; yy = qy - radius; }
+				}
+			} else {
+				bool ok = false;
+				xx = qx - radius; yy = qy - radius;
+				qy += 64; while (qy >= side) { qy -= side; ++qx; }
 				const int nowx = kpx + xx, nowy = kpy + yy;
-				if (cols || (nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2)) {      // the intervals lie inside the image
+				if (cand && nowx >= 1 && nowx <= w - 2 && nowy >= 1 && nowy <= h - 2) {
 					const float fxx = (float)xx, fyy = (float)yy;
 					if (!(fxx * fxx + fyy * fyy > fr2)) {
 						float x_rot, y_rot;
 						rotate(xx, yy, x_rot, y_rot);
 						const float ybin = (y_rot + 2.f) - 0.5f, xbin = (x_rot + 2.f) - 0.5f;
-						// between(bin, -1, 4) on floats is  -1 <= bin <= 3  (lib/utils.hh:27)
 						ok = (ybin >= -1.f && ybin <= 3.f && xbin >= -1.f && xbin <= 3.f);
 					}
 				}
+				const unsigned long long mask = __ballot(ok);
+				if (ok) S.q[(qhead + qn + rank_below(mask)) & (QCAP - 1)] = (unsigned)(xx + 128) | ((unsigned)(yy + 128) << 8);
+				qn += __popcll(mask);
+				run = qn >= 64 || (i0 + 64 >= ncand && qn > 0);
+				if (run) {
+					WAVE_FENCE();
+					const int n = qn < 64 ? qn : 64;
+					const unsigned pk = S.q[(qhead + lane) & (QCAP - 1)];
+					cand = lane < n;
+					xx = (int)(pk & 0xFFu) - 128; yy = (int)((pk >> 8) & 0xFFu) - 128;
+					qhead = (qhead + n) & (QCAP - 1); qn -= n;
+					WAVE_FENCE();
+				}
 			}
-			if (!cols) { qy += 64; while (qy >= side) { qy -= side; ++qx; } }
-			const unsigned long long mask = __ballot(ok);
-			if (ok) S.q[(qhead + qn + rank_below(mask)) & (QCAP - 1)] = (unsigned)(xx + 128) | ((unsigned)(yy + 128) << 8);
-			qn += __popcll(mask);
-			if (qn >= 64) { WAVE_FENCE(); process_batch(64); }
+			if (run) process_batch(cand, xx, yy);
 		}
-		if (qn > 0) { WAVE_FENCE(); process_batch(qn); }
 
 		// hist_to_descriptor (:15-46): L1-normalise (sequential fp32 sum), sqrt, * DESC_INT_FACTOR
 		float* hist = S.hist;

@@ -186,15 +186,14 @@ hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float
 // over their lists, any grid is correct.
 hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap, int expect,
 		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
-hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap, int expect,
-		KeyPoint* out, hipStream_t st);
 // per_image[img * OP_OCNT_STRIDE] += orientation peaks of every keypoint (atomic; one counter per 128-byte line; cleared at the start of the step)
 #define OP_OCNT_STRIDE 32
 hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap, int expect,
-		float* dirs /* n x cap x 36: histogram in, peak directions out */, int* ndirs /* n x cap */, int* per_image /* n x OP_OCNT_STRIDE */, hipStream_t st);
+		float* dirs /* n x cap x 36: histogram in, peak directions out */, int* ndirs /* n x cap */, int* per_image /* n x OP_OCNT_STRIDE */,
+		KeyPoint* sorted /* n x cap: refined in the canonical order */, int* slot_of /* n x cap: sorted position -> slot in refined */, hipStream_t st);
 // image img's keypoints land at [sum of the earlier images' counts, ...); *total = sum of all, count_out[0..n) = the counts packed
 // (device-side, no host round trip)
-hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* sorted, const int* slot_of, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const int* per_image /* n x OP_OCNT_STRIDE */, long long* total, int* count_out /* n */,
 		KeyPoint* oriented, long long oriented_cap, hipStream_t st);
 // the descriptor count is read on the device (*total); cap = capacity of the output buffers

@@ -230,52 +230,64 @@ __device__ __forceinline__ bool kp_less(const KeyPoint& a, const KeyPoint& b) {
 	return false;
 }
 
-// Rank sort into the canonical order.  Grid (cap/256, n): every thread ranks one keypoint of
-// its image against all K keypoints, whose packed 64-bit primary keys (oct, scale, y, x) are
-// staged through LDS in chunks; the full comparison only runs on primary-key ties.
+// Rank sort into the canonical order: every keypoint is ranked against all keypoints of its image, whose packed
+// 64-bit primary keys (oct, scale, y, x) are staged through LDS in chunks; the full comparison only runs on
+// primary-key ties.  The orientation histograms do not depend on the order, so the ranking is not a kernel of its own:
+// it runs on extra wavefronts of k_orientation (below), 8 keypoints x 8 lanes each, beside the histogram wavefronts,
+// and leaves the sorted list plus, per sorted position, the keypoint's slot in the unsorted list (where its
+// histogram / peaks are); k_expand_oriented reads both.
 __device__ __forceinline__ unsigned long long kp_key(const KeyPoint& k) {
 	return ((unsigned long long)(unsigned)k.oct << 48) | ((unsigned long long)(unsigned)k.scale << 40) |
 		((unsigned long long)(unsigned)(k.y & 0xFFFFF) << 20) | (unsigned long long)(unsigned)(k.x & 0xFFFFF);
 }
-constexpr int SORT_CHUNK = 2048;
+constexpr int SORT_CHUNK = 256;            // keys staged per round (2 KB of LDS)
 constexpr int SORT_SPLIT = 8;              // lanes sharing one keypoint's rank scan
-constexpr int SORT_KEYS = 256 / SORT_SPLIT;
-__global__ void __launch_bounds__(256) k_sort_refined(const KeyPoint* in, const int* count, int cap, KeyPoint* out) {
-	__shared__ unsigned long long s_key[SORT_CHUNK];
-	const int img = blockIdx.y;
-	const int n = count[img];
-	const KeyPoint* a = in + (long long)img * cap;
-	KeyPoint* b = out + (long long)img * cap;
-	for (int kb = blockIdx.x; kb * SORT_KEYS < n; kb += gridDim.x) {          // (uniform over the workgroup)
-	const int i = kb * SORT_KEYS + threadIdx.x / SORT_SPLIT, sub = threadIdx.x % SORT_SPLIT;
-	const bool live = i < n;
-	KeyPoint me;
-	if (live) me = a[i];
-	const unsigned long long mykey = live ? kp_key(me) : 0ULL;
-	int rank = 0;
-	for (int cb = 0; cb < n; cb += SORT_CHUNK) {
-		const int cn = n - cb < SORT_CHUNK ? n - cb : SORT_CHUNK;
-		__syncthreads();
-		for (int j = threadIdx.x; j < cn; j += 256) s_key[j] = kp_key(a[cb + j]);
-		__syncthreads();
-		if (live) {
-			for (int j = sub; j < cn; j += SORT_SPLIT) {      // the 8 lanes of a keypoint read 8 consecutive keys
-				const unsigned long long kj = s_key[j];
-				if (kj < mykey) ++rank;
-				else if (kj == mykey) {
-					const int gj = cb + j;
-					if (gj != i) {
-						const KeyPoint o = a[gj];
-						// identical records tie-break on the slot index: either assignment is the same output
-						rank += (kp_less(o, me) || (!kp_less(me, o) && gj < i)) ? 1 : 0;
-					}
-				}
+constexpr int SORT_KEYS = 64 / SORT_SPLIT; // keypoints per wavefront
+__device__ __forceinline__ void sort_refined_part(const KeyPoint* a, int n, KeyPoint* b, int* slot_of, int kb0, int kstride,
+		unsigned long long* s_key) {
+	const int lane = threadIdx.x;
+	for (int kb = kb0; kb * SORT_KEYS < n; kb += kstride) {          // (uniform over the wavefront)
+		const int i = kb * SORT_KEYS + lane / SORT_SPLIT, sub = lane % SORT_SPLIT;
+		const bool live = i < n;
+		KeyPoint me;
+		if (live) me = a[i];
+		const unsigned long long mykey = live ? kp_key(me) : 0ULL;
+		// branch-free scan: keys below mine, and keys equal to mine (one: myself, unless primary keys tie).  The chunk is
+		// padded with the largest key, so every lane runs the same SORT_CHUNK / 8 steps at immediate LDS offsets.
+		int rank = 0, same = 0;
+		for (int cb = 0; cb < n; cb += SORT_CHUNK) {
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < SORT_CHUNK / 64; ++q) {
+				const int j = cb + q * 64 + lane;
+				s_key[q * 64 + lane] = j < n ? kp_key(a[j]) : ~0ULL;
+			}
+			__syncthreads();
+			const unsigned long long* sk = s_key + sub;            // the 8 lanes of a keypoint read 8 consecutive keys
+#pragma unroll 8
+			for (int j = 0; j < SORT_CHUNK; j += SORT_SPLIT) {
+				const unsigned long long kj = sk[j];
+				// rank += kj < mykey; same += kj == mykey: a compare into VCC and an add-with-carry each
+				asm("v_cmp_lt_u64 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\tv_cmp_eq_u64 vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+						: "+v"(rank), "+v"(same) : "v"(kj), "v"(mykey) : "vcc");
 			}
 		}
-	}
 #pragma unroll
-	for (int off = 1; off < SORT_SPLIT; off <<= 1) rank += __shfl_xor(rank, off);
-	if (live && sub == 0) { me.src = rank; b[rank] = me; }
+		for (int off = 1; off < SORT_SPLIT; off <<= 1) { rank += __shfl_xor(rank, off); same += __shfl_xor(same, off); }
+		if (live && same > 1) {                                   // primary-key ties (rare): the full comparison against the tied records
+			int extra = 0;
+			for (int j = sub; j < n; j += SORT_SPLIT) {
+				if (j == i) continue;
+				const KeyPoint o = a[j];
+				if (kp_key(o) != mykey) continue;
+				// identical records tie-break on the slot index: either assignment is the same output
+				extra += (kp_less(o, me) || (!kp_less(me, o) && j < i)) ? 1 : 0;
+			}
+#pragma unroll
+			for (int off = 1; off < SORT_SPLIT; off <<= 1) extra += __shfl_xor(extra, off);
+			rank += extra;
+		}
+		if (live && sub == 0) { me.src = rank; b[rank] = me; slot_of[rank] = i; }
 	}
 }
 
@@ -313,7 +325,14 @@ __device__ __forceinline__ float ori_uni(float v) { return __builtin_bit_cast(fl
 #define ORI_FENCE() asm volatile("" ::: "memory")      // one wavefront per workgroup: LDS accesses execute in program order
 
 __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* __restrict__ refined, const int* __restrict__ refined_count,
-		int cap, float* __restrict__ hist_out) {
+		int cap, float* __restrict__ hist_out, int sort_blocks, KeyPoint* __restrict__ sorted, int* __restrict__ slot_of) {
+	__shared__ unsigned long long s_key[SORT_CHUNK];
+	if ((int)blockIdx.x < sort_blocks) {               // the first sort_blocks wavefronts of every image rank its keypoints
+		const long long at = (long long)blockIdx.y * cap;
+		sort_refined_part(refined + at, refined_count[blockIdx.y], sorted + at, slot_of + at, blockIdx.x, sort_blocks, s_key);
+		return;
+	}
+	const int first = blockIdx.x - sort_blocks, nblocks = gridDim.x - sort_blocks;
 	__shared__ unsigned long long s_mask[ORI_BINS];   // per bin: bit l = lane l's sample of this round falls into it
 	__shared__ __attribute__((aligned(16))) float s_sorted[64 + 3 * ORI_BINS + 12 + 4];   // the round's values, bin-major, sample order inside a bin; lists 16-byte aligned, zero-padded to float4s; last float4: zeros
 	__shared__ unsigned short s_off[64];
@@ -328,7 +347,7 @@ __global__ void __launch_bounds__(64) k_orientation(SiftPlan p, const KeyPoint* 
 	if (lane < ORI_BINS) s_mask[lane] = 0ULL;
 	if (lane < 4) s_sorted[ZERO4 * 4 + lane] = 0.f;
 	__syncthreads();
-	for (int k = blockIdx.x; k < count; k += gridDim.x) {
+	for (int k = first; k < count; k += nblocks) {
 		const KeyPoint kp = refined[(long long)img * cap + k];
 		const int kpx = ori_uni(kp.x), kpy = ori_uni(kp.y);
 		const OctDesc od = p.oct[ori_uni(kp.oct)];
@@ -503,7 +522,7 @@ __device__ __forceinline__ int exp_scan_add(int v) {
 	return v;
 }
 constexpr int EXP_T = 1024;           // one pass over a thousand keypoints per image: every dependent round trip (counts -> keypoint + peaks -> store) once
-__global__ void __launch_bounds__(EXP_T) k_expand_oriented(const KeyPoint* refined, const int* refined_count, int cap,
+__global__ void __launch_bounds__(EXP_T) k_expand_oriented(const KeyPoint* refined, const int* slot_of, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const int* per_image, int nimg, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap) {
 	__shared__ long long s_before[EXP_T], s_all[EXP_T];
 	__shared__ int s_wave[EXP_T / 64];
@@ -526,7 +545,8 @@ __global__ void __launch_bounds__(EXP_T) k_expand_oriented(const KeyPoint* refin
 	if (img == 0 && tid == 0) *total = s_all[0];
 	for (int start = 0; start < n; start += EXP_T) {
 		const int i = start + tid;
-		const int cnt = i < n ? ndirs[(long long)img * cap + i] : 0;
+		const long long at = (long long)img * cap + (i < n ? slot_of[(long long)img * cap + i] : 0);      // the keypoint's slot in the unsorted list
+		const int cnt = i < n ? ndirs[at] : 0;
 		const int incl = exp_scan_add(cnt);
 		if (lane == 63) s_wave[wave] = incl;
 		__syncthreads();
@@ -536,7 +556,7 @@ __global__ void __launch_bounds__(EXP_T) k_expand_oriented(const KeyPoint* refin
 		const long long first = base + wbase + (incl - cnt);
 		if (i < n) {
 			KeyPoint kp = refined[(long long)img * cap + i];
-			const float* d = dirs + ((long long)img * cap + i) * ORI_BINS;
+			const float* d = dirs + at * ORI_BINS;
 			for (int j = 0; j < cnt; ++j) {
 				kp.dir = d[j]; kp.src = i; kp.pad = img;      // pad carries the image index to the descriptor kernel
 				const long long slot = first + j;
@@ -558,28 +578,23 @@ hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count
 	return hipGetLastError();
 }
 
-hipError_t launch_sort_refined(const SiftPlan& p, const KeyPoint* in, const int* count, int cap, int expect,
-		KeyPoint* out, hipStream_t st) {
-	const int want = expect > 0 ? expect + expect / 4 + SORT_KEYS : cap;
-	hipLaunchKernelGGL(k_sort_refined, dim3(((want < cap ? want : cap) + SORT_KEYS - 1) / SORT_KEYS, p.n), dim3(256), 0, st, in, count, cap, out);
-	return hipGetLastError();
-}
-
 hipError_t launch_orientation(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap, int expect,
-		float* dirs, int* ndirs, int* per_image, hipStream_t st) {
+		float* dirs, int* ndirs, int* per_image, KeyPoint* sorted, int* slot_of, hipStream_t st) {
 	// ORI_GRID_X wavefronts per image striding over the (device-side) keypoint count, about two keypoints each for the
 	// thousand keypoints of a 1300 x 867 view (measured: 256 / 512 / 1024 / 2048 per image = 0.100 / 0.094 / 0.104 / 0.103 ms)
-	dim3 grid(cap < ORI_GRID_X ? cap : ORI_GRID_X, p.n);
-	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs);
+	// in front of them, per image, the wavefronts that rank the keypoints (8 each, striding: any number is correct)
+	const int want = expect > 0 ? expect + expect / 4 + 256 : cap;
+	const int sort_blocks = ((want < cap ? want : cap) + SORT_KEYS - 1) / SORT_KEYS;
+	dim3 grid(sort_blocks + (cap < ORI_GRID_X ? cap : ORI_GRID_X), p.n);
+	hipLaunchKernelGGL(k_orientation, grid, dim3(64), 0, st, p, refined, refined_count, cap, dirs, sort_blocks, sorted, slot_of);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	const int want = expect > 0 ? expect + expect / 4 + 256 : cap;       // the kernel strides: any grid is correct
 	hipLaunchKernelGGL(k_orient_peaks, dim3(((want < cap ? want : cap) + 255) / 256, p.n), dim3(256), 0, st, refined_count, cap, p.ori_smooth, dirs, ndirs, per_image);
 	return hipGetLastError();
 }
 
-hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* refined_count, int cap,
+hipError_t launch_expand_oriented(const SiftPlan& p, const KeyPoint* refined, const int* slot_of, const int* refined_count, int cap,
 		const float* dirs, const int* ndirs, const int* per_image, long long* total, int* count_out, KeyPoint* oriented, long long oriented_cap, hipStream_t st) {
-	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(EXP_T), 0, st, refined, refined_count, cap, dirs, ndirs, per_image, p.n, total, count_out, oriented, oriented_cap);
+	hipLaunchKernelGGL(k_expand_oriented, dim3(p.n), dim3(EXP_T), 0, st, refined, slot_of, refined_count, cap, dirs, ndirs, per_image, p.n, total, count_out, oriented, oriented_cap);
 	return hipGetLastError();
 }

@@ -34,7 +34,7 @@ struct DevBuf {
 }	// namespace
 
 struct Workspace {
-	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, dirs, ndirs, oriented;
+	DevBuf ws, work, srcs, staging, raw, counts, refinedA, refinedB, slot_of, dirs, ndirs, oriented;
 	void* pinned = nullptr; size_t pinned_cap = 0;   // host-pinned scratch: source pointer table, counter block
 	std::vector<const void*> srcs_last; void* srcs_dev = nullptr;   // the pointer table the device holds (and where)
 	long long last_total = 0;                        // descriptors of the previous batch: predicts output capacity
@@ -43,7 +43,7 @@ struct Workspace {
 	int desc_list_cap = OP_DESC_LIST_CAP;            // list arena of the descriptor kernel's sorting pass (op_debug_set_desc_list_cap)
 	void release() {
 		ws.release(); work.release(); srcs.release(); staging.release(); raw.release(); counts.release();
-		refinedA.release(); refinedB.release(); dirs.release(); ndirs.release(); oriented.release();
+		refinedA.release(); refinedB.release(); slot_of.release(); dirs.release(); ndirs.release(); oriented.release();
 		if (pinned) hipHostFree(pinned); pinned = nullptr; pinned_cap = 0;
 		srcs_last.clear(); srcs_dev = nullptr;
 	}
@@ -244,6 +244,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	HIPCHK(W.refinedB.ensure(sizeof(KeyPoint) * (size_t)cap * n));
 	HIPCHK(W.dirs.ensure(sizeof(float) * 36 * (size_t)cap * n));
 	HIPCHK(W.ndirs.ensure(sizeof(int) * (size_t)cap * n));
+	HIPCHK(W.slot_of.ensure(sizeof(int) * (size_t)cap * n));
 	const size_t pin_need = sizeof(long long) * (size_t)(8 * n + 16);
 	if (W.pinned_cap < pin_need) {
 		if (W.pinned) hipHostFree(W.pinned);
@@ -304,10 +305,10 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 	{ ProfScope ps(ctx, "resize + octave grey"); HIPCHK(launch_grey_octaves(plan, keep != nullptr, st)); }
 	{ ProfScope ps(ctx, "build pyramid"); HIPCHK(launch_pyramid(plan, (int*)W.raw.p, d_raw_count, cap, st)); }
 	{ ProfScope ps(ctx, "extrema refine");
-	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, W.last_raw_max, (KeyPoint*)W.refinedA.p, d_refined_count, st));
-	  HIPCHK(launch_sort_refined(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, W.last_refined_max, (KeyPoint*)W.refinedB.p, st)); }
-	{ ProfScope ps(ctx, "orientation");
-	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, W.last_refined_max, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt, st)); }
+	  HIPCHK(launch_refine(plan, (const int*)W.raw.p, d_raw_count, cap, W.last_raw_max, (KeyPoint*)W.refinedA.p, d_refined_count, st)); }
+	{ ProfScope ps(ctx, "orientation");       // histograms + peaks on the unsorted list; the canonical order (refinedB, slot_of) beside them
+	  HIPCHK(launch_orientation(plan, (const KeyPoint*)W.refinedA.p, d_refined_count, cap, W.last_refined_max, (float*)W.dirs.p, (int*)W.ndirs.p, d_ocnt,
+				(KeyPoint*)W.refinedB.p, (int*)W.slot_of.p, st)); }
 
 	// The descriptor count is only known on the device at this point.  Instead of a round trip,
 	// the output buffers get a capacity predicted from the previous call of this context (x1.25,
@@ -324,7 +325,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 		HIPCHK(pool_alloc((void**)&res.coor, sizeof(double) * 2 * (size_t)capK));
 		HIPCHK(pool_alloc((void**)&res.real, sizeof(double) * 2 * (size_t)capK));
 		{ ProfScope ps(ctx, "orientation");
-		  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, d_refined_count, cap, (const float*)W.dirs.p,
+		  HIPCHK(launch_expand_oriented(plan, (const KeyPoint*)W.refinedB.p, (const int*)W.slot_of.p, d_refined_count, cap, (const float*)W.dirs.p,
 					(const int*)W.ndirs.p, d_ocnt, d_total, d_oriented_count, (KeyPoint*)W.oriented.p, capK, st)); }
 		{ ProfScope ps(ctx, "sift descriptor");
 		  HIPCHK(launch_descriptor(plan, (const KeyPoint*)W.oriented.p, d_total, capK, res.desc, res.coor, res.real, st)); }
