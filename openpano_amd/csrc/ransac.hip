@@ -135,7 +135,6 @@ constexpr int RS_BLK = 9;                  // generator blocks per chunk (38 KB 
 constexpr int RS_N = RS_BLK * 624;         // 5616 draws; 1500 hypotheses of 8 need ~12.4 k at m ~ 100: a few chunks, each sized to what is left
 constexpr int RS_SMAX = 1024;              // > RS_N / 7 + 2 hypothesis starts per chunk
 constexpr int RS_W = 16;                   // draws of a sample walk that are pre-loaded into registers
-constexpr int RS_LB = 24;                  // look-back of the previous-equal-draw table; longer samples take the exact walk
 constexpr unsigned short RS_END = 0xFFFF;  // "no complete sample starts here"
 
 // Walk the sample that starts at stream position i: ns distinct values in draw order (v[]), returns
@@ -217,31 +216,79 @@ __device__ __forceinline__ int rs_walk_mask(const unsigned short* rd, int i, int
 	return end;
 }
 
-// next(i) through the previous-equal-draw table: PP[t] = 1 + position of the nearest earlier draw
-// with the same value within RS_LB positions, 0 if none.  Inside the sample that starts at i, draw t
-// is a repeat exactly if an equal draw lies in [i, t) -- i.e. PP[t] > i (if the nearest equal draw
-// inside the sample was itself rejected, an earlier equal one was accepted) -- so the walk is one
-// compare per draw.  Valid while the sample spans at most RS_LB positions; longer ones (many
-// rejections: tiny m) return -2 and take the exact value-comparing walk.
-__device__ __forceinline__ int rs_next_fast(const unsigned short* PP, int i, int N, int ns) {
-	int cnt = 0, end = -1;
-	unsigned short w[RS_W];
+// next(i) for ALL start positions of a chunk.  The sample that starts at i accepts the first NS distinct values of
+// rd[i..): next(i) - 1 is the position where the NS-th distinct value first occurs.  Keep, for the current i, the
+// distinct values to the right ordered by their first occurrence (val[0] at pos[0] the nearest): stepping from i + 1
+// to i moves x = rd[i] to the front -- it is taken out of the list where it stood (or the last entry drops off) and
+// everything in front of that place moves one back.  So one thread walks a segment of starts right to left at one
+// list update (NS compares, NS conditional moves of a value and a position) per start, instead of one whole sample
+// walk per start; the list at the segment's right end is the sample walked forward from there (first occurrences in
+// order), or, when the chunk ends before NS distinct values were seen, the same right-to-left walk from the chunk's end.
+// Any m: values are compared directly.  The result is next(i) of the sequential rejection loop
+// (transform_estimate.cc:70-77) for every i, END where the chunk ends first.
+constexpr int RS_SEG = 24;                 // start positions per thread (a thread pays one forward sample walk for its segment)
+template <int NS>
+__device__ __forceinline__ void rs_next_table(const unsigned short* rd, unsigned short* J, int N, int ns_rt, int tid) {
+	const int ns = NS ? NS : ns_rt;        // NS = 0: run-time sample size (<= 8)
+	const int a0 = tid * RS_SEG;
+	if (tid == 0) J[N] = RS_END;
+	if (a0 >= N) return;
+	const int b = a0 + RS_SEG < N ? a0 + RS_SEG : N;
+	int val[8], pos[8];
 #pragma unroll
-	for (int j = 0; j < RS_W; ++j) w[j] = PP[i + j];                  // PP is padded past N
+	for (int q = 0; q < 8; ++q) { val[q] = -1; pos[q] = 0; }
+	int cnt = 0;
+	// x moves to the front of the list: entry q takes entry q - 1 while x was not met in front of q
+	auto to_front = [&](int x, int at) {
+		int pv = val[0], pp = pos[0];      // the entry that stood one place in front
+		bool c = true, absent = true;      // x not met in front of q; x is none of the first ns entries
+		val[0] = x; pos[0] = at;
 #pragma unroll
-	for (int j = 0; j < RS_W; ++j) {
-		const bool take = cnt < ns && i + j < N && (int)w[j] <= i;
-		cnt += take ? 1 : 0;
-		end = (take && cnt == ns) ? i + j + 1 : end;
+		for (int q = 1; q < 8; ++q) {
+			c = c && pv != x;
+			absent = (q == ns) ? c : absent;
+			const int tv = val[q], tp = pos[q];
+			val[q] = c ? pv : tv; pos[q] = c ? pp : tp;
+			pv = tv; pp = tp;
+		}
+		if (ns == 8) absent = c && pv != x;
+		cnt += (absent && cnt < ns) ? 1 : 0;
+	};
+	// the list at b: the sample that starts at b, walked forward; new values go to the FRONT here (newest first) ...
+	int t = b;
+	while (t < N && cnt < ns) {
+		const int x = rd[t];
+		bool isnew = true;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) isnew = isnew && val[q] != x;
+		if (isnew) {
+#pragma unroll
+			for (int q = 7; q >= 1; --q) { val[q] = val[q - 1]; pos[q] = pos[q - 1]; }
+			val[0] = x; pos[0] = t; ++cnt;
+		}
+		++t;
 	}
-	if (cnt < ns) {
-		int j = i + RS_W;
-		const int lim = i + RS_LB < N ? i + RS_LB : N;
-		while (cnt < ns && j < lim) { cnt += (int)PP[j] <= i ? 1 : 0; ++j; }
-		if (cnt == ns) end = j;
-		else end = j >= N ? -1 : -2;               // chunk exhausted : sample longer than the look-back
+	if (cnt == ns) {
+		// ... and the first ns entries are turned round into first-occurrence order
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+#pragma unroll
+			for (int r = q + 1; r < 8; ++r)
+				if (q + r == ns - 1) { const int tv = val[q], tp = pos[q]; val[q] = val[r]; pos[q] = pos[r]; val[r] = tv; pos[r] = tp; }
+	} else {
+		// the chunk ended first: fewer than ns distinct values in [b, N); their list, by the right-to-left walk
+#pragma unroll
+		for (int q = 0; q < 8; ++q) val[q] = -1;
+		cnt = 0;
+		for (int i = N - 1; i >= b; --i) to_front((int)rd[i], i);
 	}
-	return end;
+	for (int i = b - 1; i >= a0; --i) {
+		to_front((int)rd[i], i);
+		int last = pos[7];
+#pragma unroll
+		for (int q = 0; q < 7; ++q) last = (q == ns - 1) ? pos[q] : last;
+		J[i] = cnt >= ns ? (unsigned short)(last + 1) : RS_END;
+	}
 }
 
 // std::mt19937::seed for every pair at once (thread per pair; the recurrence is serial in i)
@@ -311,31 +358,9 @@ __global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restr
 		const int N = carry + nb * 624;
 		__syncthreads();
 		// ---- next(i) for every start position; next(N) = END ----
-		if (m <= 64) {
-			for (int i = tid; i <= N; i += RS_T) {
-				int v[8];
-				const int e = i < N ? rs_walk_mask<false>(rd, i, N, ns, v) : -1;
-				Ja[i] = e < 0 ? RS_END : (unsigned short)e;
-			}
-		} else {
-			// previous-equal-draw table (into Jb) first
-			for (int t = tid; t < N + RS_W; t += RS_T) {
-				int dd = 0;
-				if (t < N) {
-					const int x = rd[t];
-					const int lb = t < RS_LB ? t : RS_LB;
-#pragma unroll
-					for (int d = RS_LB; d >= 1; --d) dd = (d <= lb && (int)rd[t - (d <= lb ? d : 0)] == x) ? d : dd;     // the nearest match wins
-				}
-				Jb[t] = dd ? (unsigned short)(t - dd + 1) : (unsigned short)0;
-			}
-			__syncthreads();
-			for (int i = tid; i <= N; i += RS_T) {
-				int e = i < N ? rs_next_fast(Jb, i, N, ns) : -1;
-				if (e == -2) { int v[8]; e = rs_walk(rd, i, N, ns, v); }
-				Ja[i] = e < 0 ? RS_END : (unsigned short)e;
-			}
-		}
+		if (ns == 8) rs_next_table<8>(rd, Ja, N, ns, tid);
+		else if (ns == 7) rs_next_table<7>(rd, Ja, N, ns, tid);
+		else rs_next_table<0>(rd, Ja, N, ns, tid);
 		if (tid == 0) { S[0] = 0; s_cnt = 0; }
 		int maxS = N / ns + 2; maxS = maxS < RS_SMAX ? maxS : RS_SMAX;
 		unsigned short* J = Ja; unsigned short* Jn = Jb;
