@@ -227,6 +227,7 @@ __device__ __forceinline__ int rs_walk_mask(const unsigned short* rd, int i, int
 // Any m: values are compared directly.  The result is next(i) of the sequential rejection loop
 // (transform_estimate.cc:70-77) for every i, END where the chunk ends first.
 constexpr int RS_SEG = 24;                 // start positions per thread (a thread pays one forward sample walk for its segment)
+static_assert(RS_SEG * RS_T >= RS_N, "rs_next_table: one segment per thread must cover a chunk");
 template <int NS>
 __device__ __forceinline__ void rs_next_table(const unsigned short* rd, unsigned short* J, int N, int ns_rt, int tid) {
 	const int ns = NS ? NS : ns_rt;        // NS = 0: run-time sample size (<= 8)
