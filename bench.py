@@ -26,7 +26,8 @@ in the same line; under a weak headline ``strong_config4`` carries the strong-sc
 The JSON line also carries
   configs       BASELINE.json's other configurations, driver-timed in the same invocation (bench_configs.py): "2" (11 ordered
                 600x400), "3" (13 ordered 1500x1112), "4_natural" (config 4 on the natural-texture crops SURVEY 8(d) names;
-                `value_natural` repeats its keypoints+descriptors/s next to `value`), each with its own parity block,
+                `value_natural` repeats its keypoints+descriptors/s next to `value`), each with its own parity block; "4" and
+                "5" are index entries pointing at the headline sections and at `config5`,
   roofline      live HIP-event timing of the dominant kernel vs its algorithmic HBM bytes,
   cpu_baseline  the reference's CPU path (oracle/_ref when it travelled, else the C oracle) timed
                 on this box's host cores on a bounded sample of the same images (rank 0, N=1),
@@ -602,6 +603,19 @@ def main():
         if not args.no_config5:
             out["config5"] = run_strong_job(hip, ctx, cfg, "config5", args, dist, dev, rank, world, barrier, log,
                                             parity=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+
+    # configs "4" and "5": index entries, so that every BASELINE configuration is found under one key -- config 4 IS the
+    # headline (top level of this line), config 5 the strong-scaled job in `config5`
+    if rank == 0 and "configs" in out:
+        out["configs"]["4"] = {"workload": out["config"]["workload"], "keypoints_per_s": value, "sift_ms_per_step": out["ms_per_step"],
+                               "image_pairs_per_s": (out.get("match") or {}).get("image_pairs_per_s"),
+                               "ransac_image_pairs_per_s": (out.get("ransac") or {}).get("image_pairs_per_s"),
+                               "see": "top level of this line: value, stage_ms, roofline, match, ransac, blend, stitch_e2e, protocol, parity"}
+        if "config5" in out:
+            c5 = out["config5"]
+            out["configs"]["5"] = {"workload": c5.get("workload"), "phase_ms": c5.get("phase_ms"), "keypoints_per_s": c5.get("keypoints_per_s"),
+                                   "image_pairs_per_s": c5.get("image_pairs_per_s"), "match_roofline_frac": (c5.get("match_roofline") or {}).get("frac"),
+                                   "see": "config5 (the whole job, with its parity block)"}
 
     # ---------------- CPU baseline + parity of the timed run (rank 0, N=1 only) ----------------
     rc = 0
