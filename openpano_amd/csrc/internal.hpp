@@ -182,8 +182,8 @@ hipError_t launch_pyramid(const SiftPlan& p, int* raw /* n x cap x 4 */, int* ra
 hipError_t launch_magort_plane(const SiftPlan& p, int img, int oct, int s, float* mag, float* ort, hipStream_t st);
 // expect = the largest per-image list length seen in the previous batch (0: unknown).  Workgroups cost dispatcher time
 // whether they find work or not (k_refine over the whole 16 K capacity: 4864 workgroups for 30 busy ones per image took
-// 35 us more than a grid sized to the lists), so these two launch as many as the expectation needs; both kernels stride
-// over their lists, any grid is correct.
+// 35 us more than a grid sized to the lists), so k_refine, the ranking wavefronts of k_orientation and k_orient_peaks get as
+// many workgroups as the expectation needs; all of them stride over their lists, any grid is correct.
 hipError_t launch_refine(const SiftPlan& p, const int* raw, const int* raw_count, int cap, int expect,
 		KeyPoint* refined /* n x cap */, int* refined_count, hipStream_t st);
 // per_image[img * OP_OCNT_STRIDE] += orientation peaks of every keypoint (atomic; one counter per 128-byte line; cleared at the start of the step)
