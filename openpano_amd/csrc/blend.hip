@@ -18,11 +18,14 @@
 // resolution, homo_inv per image).
 //
 // Numerics: coordinates in fp64 exactly in the reference's operation order (this TU is built
-// with -ffp-contract=off); sin/cos/tan are the device's fp64 libm, which can differ from glibc
-// in the last ulp -- after the reference's own narrowing of coordinates to float that is
-// invisible except on measure-zero boundaries, hence the 1e-4 pixel tolerance north_star states
-// (tests assert it, and report the exact-equal fraction).  Colour arithmetic is fp32 in the
-// reference's order, so equal coordinates give bit-equal pixels.
+// with -ffp-contract=off).  The map's transcendentals are SEPARABLE: proj2homo takes sin / cos of a value that
+// depends on the canvas column only and tan of one that depends on the row only (stitcher_image.cc:144-145:
+// c = Vec2D(t.x, t.y) * resolution + proj_range.min), and CylinderProject's tan / cos (warp.cc:19-23) take a
+// per-column argument.  They are therefore tabulated once per canvas by the HOST libm -- W + H evaluations of the
+// very functions the reference calls, instead of W x H evaluations of a device libm that can differ from glibc in
+// the last ulp (rounds 1-4: masks equal up to 2e-5 of the pixels, colours within 1e-4) -- and the kernels read the
+// tables: every coordinate is the reference's double, bit for bit.  Colour arithmetic is fp32 in the reference's
+// order, so the canvas is bit-equal for every projection (tests assert array equality).
 #include "internal.hpp"
 #include <algorithm>
 #include <cfloat>
@@ -48,11 +51,16 @@ struct BlendImg {
 
 struct BlendGeom { int method; double minx, miny, resx, resy; };
 
-// stitch/projection.hh:29-31,38-40,66-68
-__device__ __forceinline__ void proj2homo(int method, double x, double y, double& hx, double& hy, double& hz) {
-	if (method == 0) { hx = x; hy = y; hz = 1.0; }
-	else if (method == 1) { hx = sin(x); hy = y; hz = cos(x); }
-	else { hx = sin(x); hy = tan(y); hz = cos(x); }
+// stitch/projection.hh:29-31,38-40,66-68 for canvas pixel (i, j).  Flat: the coordinates themselves.  Cylindrical /
+// spherical: colsc[j] = (sin, cos) of the column's x, rowt[i] = y (cylindrical) or tan(y) (spherical), from the host
+// libm (trig_tables below); the tables have one entry past the canvas (the multiband first level visits it).
+struct BlendTrig { const double2* colsc; const double* rowt; int w1, h1; };
+__device__ __forceinline__ void proj2homo(const BlendGeom& g, const BlendTrig& t, int i, int j, double& hx, double& hy, double& hz) {
+	if (g.method == 0) { hx = (double)j * g.resx + g.minx; hy = (double)i * g.resy + g.miny; hz = 1.0; }
+	else {
+		const double2 sc = t.colsc[j < t.w1 ? j : t.w1 - 1];
+		hx = sc.x; hz = sc.y; hy = t.rowt[i < t.h1 ? i : t.h1 - 1];
+	}
 }
 
 // the lambda of ConnectedImages::blend (stitcher_image.cc:143-151) after proj2homo
@@ -126,16 +134,14 @@ __device__ __forceinline__ void walk_cover(const unsigned long long* s_cover, in
 }
 
 // ---- LinearBlender::run (blender.cc:24-96): thread per canvas pixel, images in index order ----
-__global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, const BlendImg* __restrict__ imgs, int n,
+__global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, BlendTrig trig, const BlendImg* __restrict__ imgs, int n,
 		float* __restrict__ out, int H, int W, int ordered_input, int lazy) {
 	__shared__ unsigned long long s_cover[COVER_WORDS];
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
 	const bool live = i < H && j < W;
-	const double cx = (double)j * g.resx + g.minx;
-	const double cy = (double)i * g.resy + g.miny;
 	double hx, hy, hz;
-	proj2homo(g.method, cx, cy, hx, hy, hz);
+	proj2homo(g, trig, i, j, hx, hy, hz);
 	float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
 	for (int k0 = 0; k0 < n; k0 += COVER_WORDS * 64) {
 		tile_cover(imgs, k0, n, blockIdx.y * 4, blockIdx.x * 64, lazy ? 1 : 0, s_cover);
@@ -179,7 +185,7 @@ __global__ void __launch_bounds__(256) k_blend_linear(BlendGeom g, const BlendIm
 // the winner's weight is then set to 1 with one 4-byte store.  The ROI planes are written once and never read back
 // (the two-kernel form re-read every weight and rewrote it: 0.49 GB of the 1.33 GB the two kernels moved), and the
 // target canvas / its "seen" mask are initialised here too (fill(target, Color::NO), multiband.cc:60-61).
-__global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, const BlendImg* __restrict__ imgs, int n,
+__global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, BlendTrig trig, const BlendImg* __restrict__ imgs, int n,
 		float4* __restrict__ cur, unsigned char* __restrict__ mask, float* __restrict__ out, unsigned char* __restrict__ tmask, int H, int W) {
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -190,10 +196,8 @@ __global__ void __launch_bounds__(256) k_mb_first_fused(BlendGeom g, const Blend
 	__shared__ unsigned long long s_cover[COVER_WORDS];
 	const bool live = !(i > H || j > W);
 	const bool inside = i < H && j < W;
-	const double cx = (double)j * g.resx + g.minx;
-	const double cy = (double)i * g.resy + g.miny;
 	double hx, hy, hz;
-	proj2homo(g.method, cx, cy, hx, hy, hz);
+	proj2homo(g, trig, i, j, hx, hy, hz);
 	float mx = 0.f; long long maxe = -1;
 	for (int k0 = 0; k0 < n; k0 += COVER_WORDS * 64) {
 		tile_cover(imgs, k0, n, blockIdx.y * 4, blockIdx.x * 64, 0, s_cover);
@@ -450,15 +454,17 @@ __global__ void __launch_bounds__(256) k_mb_bands(const BlendImg* __restrict__ i
 }
 
 // ---- CylinderProject::project (stitch/warp.cc:25-44): thread per output pixel ----
+// coltc[j] = (tan, cos) of the column's angle (j - offset.x) * sizefactor_inv, from the host libm (cyl_tables below)
 struct CylParams { double cx, cy, offx, offy, sizefactor_inv; int r; };
-__global__ void __launch_bounds__(256) k_cyl_project(CylParams P, const float* __restrict__ img, int h, int w,
+__global__ void __launch_bounds__(256) k_cyl_project(CylParams P, const double2* __restrict__ coltc, const float* __restrict__ img, int h, int w,
 		float* __restrict__ out, int nh, int nw) {
 	const int j = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
 	if (i >= nh || j >= nw) return;
-	const double px = ((double)j - P.offx) * P.sizefactor_inv, py = ((double)i - P.offy) * P.sizefactor_inv;
-	const double ox = (double)P.r * tan(px) + P.cx;                 // proj_r (warp.cc:19-23)
-	const double oy = py * (double)P.r / cos(px) + P.cy;
+	const double py = ((double)i - P.offy) * P.sizefactor_inv;
+	const double2 tc = coltc[j];
+	const double ox = (double)P.r * tc.x + P.cx;                    // proj_r (warp.cc:19-23)
+	const double oy = py * (double)P.r / tc.y + P.cy;
 	float c[3] = {-1.f, -1.f, -1.f};
 	// between(a, b, c) = a >= b && a <= c - 1 (lib/utils.hh:27)
 	if (ox >= 0 && ox <= (double)(w - 1) && oy >= 0 && oy <= (double)(h - 1))
@@ -660,6 +666,56 @@ void cyl_proj(const CylProj& P, double px, double py, double out[2]) {       // 
 
 struct Freer { std::vector<void*> v; ~Freer() { for (void* p : v) pool_free(p); } };
 
+// The transcendentals of the canvas -> space map, evaluated by the host libm exactly where the reference evaluates
+// them (stitcher_image.cc:144-145 + projection.hh:38-40,66-68): per column j  sin / cos of  j * resolution.x + min.x,
+// per row i  tan of  i * resolution.y + min.y  (spherical) or that value itself (cylindrical).  (w1, h1) = canvas + 1.
+// Layout: [w1 x (sin, cos)][h1 x row value].  Kept on the context while the geometry stays the same.
+hipError_t trig_tables(op_ctx* ctx, const BlendGeom& g, int w1, int h1, BlendTrig* out) {
+	op_ctx::TrigTables& T = ctx->blend_trig;
+	const bool hit = T.method == g.method && T.w1 == w1 && T.h1 == h1 && T.minx == g.minx && T.miny == g.miny && T.resx == g.resx && T.resy == g.resy && T.dev.p;
+	if (!hit) {
+		T.method = -1;
+		T.host.resize((size_t)2 * w1 + h1);
+		double* col = T.host.data(); double* row = col + (size_t)2 * w1;
+		const int chunks = (w1 + h1 + 1023) / 1024;
+		auto fill = [&](int c) {
+			const int a = c * 1024, b = std::min(w1 + h1, a + 1024);
+			for (int e = a; e < b; ++e) {
+				if (e < w1) { const double x = (double)e * g.resx + g.minx; col[2 * e] = std::sin(x); col[2 * e + 1] = std::cos(x); }
+				else { const int i = e - w1; const double y = (double)i * g.resy + g.miny; row[i] = g.method == 2 ? std::tan(y) : y; }
+			}
+		};
+		if (chunks > 2) host_parallel_for(chunks, fill); else for (int c = 0; c < chunks; ++c) fill(c);
+		hipError_t e = T.dev.ensure(sizeof(double) * T.host.size());
+		if (e != hipSuccess) return e;
+		e = hipMemcpyAsync(T.dev.p, T.host.data(), sizeof(double) * T.host.size(), hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the host vector may be rewritten by the next miss
+		if (e != hipSuccess) return e;
+		T.method = g.method; T.w1 = w1; T.h1 = h1; T.minx = g.minx; T.miny = g.miny; T.resx = g.resx; T.resy = g.resy;
+	}
+	out->colsc = (const double2*)T.dev.p; out->rowt = (const double*)T.dev.p + (size_t)2 * w1; out->w1 = w1; out->h1 = h1;
+	return hipSuccess;
+}
+// CylinderProject::project's per-column tan / cos (warp.cc:19-23,31): [nw x (tan, cos)]
+hipError_t cyl_tables(op_ctx* ctx, double offx, double sizefactor_inv, int nw, const double2** out) {
+	op_ctx::TrigTables& T = ctx->cyl_trig;
+	const bool hit = T.method == 3 && T.w1 == nw && T.minx == offx && T.resx == sizefactor_inv && T.dev.p;
+	if (!hit) {
+		T.method = -1;
+		T.host.resize((size_t)2 * nw);
+		double* col = T.host.data();
+		for (int j = 0; j < nw; ++j) { const double px = ((double)j - offx) * sizefactor_inv; col[2 * j] = std::tan(px); col[2 * j + 1] = std::cos(px); }
+		hipError_t e = T.dev.ensure(sizeof(double) * T.host.size());
+		if (e != hipSuccess) return e;
+		e = hipMemcpyAsync(T.dev.p, T.host.data(), sizeof(double) * T.host.size(), hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) return e;
+		T.method = 3; T.w1 = nw; T.minx = offx; T.resx = sizefactor_inv;
+	}
+	*out = (const double2*)T.dev.p;
+	return hipSuccess;
+}
+
 }	// namespace
 
 extern "C" {
@@ -777,11 +833,17 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 	if (pool_alloc((void**)&cv->data, sizeof(float) * 3 * (size_t)H * W) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_blend: canvas allocation failed"); }
 	const BlendGeom bg{g->proj_method, g->proj_min[0], g->proj_min[1], g->resolution[0], g->resolution[1]};
 	const dim3 cgrid((W + 63) / 64, (H + 3) / 4);
+	BlendTrig trig{nullptr, nullptr, 0, 0};
+	if (bg.method != 0) {
+		HostScope hs(ctx, "blend trig tables (host)");
+		hipError_t e = trig_tables(ctx, bg, W + 1, H + 1, &trig);
+		if (e != hipSuccess) { pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_blend: trig tables: ") + hipGetErrorString(e)); }
+	}
 #define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { op_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
 	pool_free(cv->data); delete cv; return OP_ERR_HIP; } } while (0)
 	if (cfg->MULTIBAND <= 0) {
 		ProfScope ps(ctx, "blend linear");
-		hipLaunchKernelGGL(k_blend_linear, cgrid, dim3(256), 0, st, bg, d_imgs, n, cv->data, H, W, cfg->ORDERED_INPUT, cfg->LAZY_READ);
+		hipLaunchKernelGGL(k_blend_linear, cgrid, dim3(256), 0, st, bg, trig, d_imgs, n, cv->data, H, W, cfg->ORDERED_INPUT, cfg->LAZY_READ);
 		BCHK(hipGetLastError());
 	} else {
 		const int L = cfg->MULTIBAND;
@@ -797,7 +859,7 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 		BCHK(pool_alloc((void**)&tmask, (size_t)H * W)); fr.v.push_back(tmask);
 		const dim3 rgrid((unsigned)((max_roi + 255) / 256), n);
 		{ ProfScope ps(ctx, "multiband first level");
-		  hipLaunchKernelGGL(k_mb_first_fused, dim3((W + 1 + 63) / 64, (H + 1 + 3) / 4), dim3(256), 0, st, bg, d_imgs, n, lv[0], mask, cv->data, tmask, H, W);
+		  hipLaunchKernelGGL(k_mb_first_fused, dim3((W + 1 + 63) / 64, (H + 1 + 3) / 4), dim3(256), 0, st, bg, trig, d_imgs, n, lv[0], mask, cv->data, tmask, H, W);
 		  BCHK(hipGetLastError()); }
 		bool band0_done = false;                 // level 0's band written by the fused blur
 		for (int level = 0; level < L; ++level) {
@@ -981,8 +1043,11 @@ int op_cyl_warp(op_ctx* ctx, const op_config* cfg, const op_image* img, double h
 	cv->h = nh; cv->w = nw; cv->device = ctx->device;
 	if (pool_alloc((void**)&cv->data, sizeof(float) * 3 * (size_t)nh * nw) != hipSuccess) { delete cv; OP_FAIL(OP_ERR_HIP, "op_cyl_warp: allocation failed"); }
 	const CylParams cp{P.cx, P.cy, off[0], off[1], 1.0 / P.sizefactor, P.r};
+	const double2* coltc = nullptr;
+	{ hipError_t e = cyl_tables(ctx, cp.offx, cp.sizefactor_inv, nw, &coltc);
+	  if (e != hipSuccess) { pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_cyl_warp: trig table: ") + hipGetErrorString(e)); } }
 	{ ProfScope ps(ctx, "cylinder warp");
-	  hipLaunchKernelGGL(k_cyl_project, dim3((nw + 63) / 64, (nh + 3) / 4), dim3(256), 0, st, cp, src, img->h, img->w, cv->data, nh, nw); }
+	  hipLaunchKernelGGL(k_cyl_project, dim3((nw + 63) / 64, (nh + 3) / 4), dim3(256), 0, st, cp, coltc, src, img->h, img->w, cv->data, nh, nw); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (e != hipSuccess) { pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_HIP, std::string("op_cyl_warp: ") + hipGetErrorString(e)); }

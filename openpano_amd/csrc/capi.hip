@@ -229,6 +229,7 @@ void op_ctx_destroy(op_ctx* c) {
 	hipStreamSynchronize(c->stream);
 	op_ctx_release_workspace(c);
 	c->match_arena.release(); c->ransac_arena.release();
+	c->blend_trig.dev.release(); c->cyl_trig.dev.release();
 	pool_trim();
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);

@@ -50,6 +50,12 @@ struct op_ctx {
 		void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 	};
 	DevScratch match_arena, ransac_arena;
+	// blend: the canvas -> space map's transcendentals, tabulated per canvas column / row by the HOST libm (blend.hip,
+	// trig_tables): kept across calls with the same canvas geometry
+	struct TrigTables {
+		int method = -1, w1 = 0, h1 = 0; double minx = 0, miny = 0, resx = 0, resy = 0;
+		DevScratch dev; std::vector<double> host;
+	} blend_trig, cyl_trig;
 	// copy streams of the host-image pipeline (op_sift_batch_host): uploads run ahead of the kernels, results leave behind them
 	hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 	hipError_t copy_streams() {

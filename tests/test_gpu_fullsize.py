@@ -115,11 +115,8 @@ def test_config4_whole_job_equals_oracle(ctx, oracle, cfg):
         cv = hip.blend(ctx, bcfg, views, homos, 2, n // 2)
         gotc = cv.numpy(); cv.free()
         assert gotc.shape == wantc.shape
-        no_g, no_w = gotc[..., 0] < 0, wantc[..., 0] < 0
-        assert (no_g != no_w).mean() <= 2e-5
-        both = ~(no_g | no_w)
-        diff = np.abs(gotc[both] - wantc[both])
-        assert diff.max() <= 1e-4 and (diff == 0).mean() > 0.999, (mb, float(diff.max()))
+        # bit-exact: the map's sin / cos / tan come from host-libm tables per canvas column / row (csrc/blend.hip)
+        assert np.array_equal(gotc, wantc), (mb, int((gotc != wantc).sum()))
 
 
 def test_config4_natural_texture_whole_job(ctx, oracle, cfg):
