@@ -46,7 +46,7 @@ def _reduce(dist, dev, tmax_vals, sum_vals):
     return [float(x) for x in t], [float(x) for x in s]
 
 
-def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, world, barrier, log):
+def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, world, barrier, log, keep_ransac_inputs=False):
     """Timed loops over the features the SIFT loop of bench.py left in HBM."""
     from openpano_amd.distributed import HipEngine, ShardedJob
     eng = HipEngine(ctx, cfg, dev)
@@ -114,6 +114,9 @@ def run_job_loops(hip, ctx, cfg, feats, n_total, shapes, args, dist, dev, rank, 
         assert len(allres) == n_total * (n_total - 1) // 2
     else:
         res["match_results_gather_ms"] = None
+    if keep_ransac_inputs:          # bench.py's CPU baseline of the RANSAC loop runs over exactly these lists
+        res["_ransac_inputs"] = ([np.asarray(m, np.int32).reshape(-1, 2) for m in job.lists], list(mine),
+                                 [feats.get(i)[1] for i in range(n_total)], list(shapes))
     job.close()
     return res
 
@@ -244,20 +247,29 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
         allt = torch.empty(world * len(names), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allt, mine_t)
         per_rank = [{x: round(float(v), 4) for x, v in zip(names, row)} for row in allt.view(world, len(names)).cpu()]
+    # At N > 1 the pairs of two own images are matched INSIDE the 'feature all-gather' lap (ShardedJob(overlap=True)), the
+    # rest in 'match': the match rates divide ALL pairs by the sum of the two laps (dividing by 'match' alone would credit
+    # that lap with pairs it did not handle -- 12 % of them at N = 8 on config 5).  N = 1: no own-pair pass, 'match' alone.
+    overlapped = world > 1 and len(job.local_sel) > 0
+    match_span = phm["match"] + (phm["feature all-gather"] if overlapped else 0.0)
+    match_span_note = "feature all-gather + match (own pairs are matched during the exchange)" if overlapped else "match"
     res = {"workload": f"{what}; ONE job dealt round-robin over {world} GPU(s); inputs resident in HBM", "scaling": "strong",
            "images": n, "image": [H, W], "n_gpus": world, "descriptors": int(sm[0]), "keypoints_per_image": sm[0] / n,
            "image_pairs": int(sm[1]), "matches": int(sm[2]), "accepted_pairs": int(sm[3]), "inliers": int(sm[4]),
            "phase_ms": {x: round(v, 4) for x, v in phm.items()}, "per_rank_phase_ms": per_rank, "job_wall_ms": tm[-1],
            "own_pairs_matched_during_exchange": len(job.local_sel),
-           "keypoints_per_s": sm[0] / (phm["sift"] * 1e-3), "image_pairs_per_s": sm[1] / (phm["match"] * 1e-3),
-           "matches_per_s": sm[2] / (phm["match"] * 1e-3), "ransac_image_pairs_per_s": sm[1] / (phm["ransac"] * 1e-3),
+           "keypoints_per_s": sm[0] / (phm["sift"] * 1e-3), "image_pairs_per_s": sm[1] / (match_span * 1e-3),
+           "matches_per_s": sm[2] / (match_span * 1e-3), "ransac_image_pairs_per_s": sm[1] / (phm["ransac"] * 1e-3),
+           "match_rate_span": match_span_note,
            "match_stage_ms": {x: round(v, 4) for x, v in prof.items() if x.startswith("matcher")},
            "sift_stage_ms": {x: round(v, 4) for x, v in prof.items() if not x.startswith("matcher")},
            "match_roofline": _mfma_roofline(prof, flops, getattr(args, "pmc", None), getattr(args, "pmc_src", None)),
            "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
     if parity and world == 1:
         t0 = time.perf_counter()
-        res["parity"] = job_parity(hip, ctx, cfg, job, d_imgs, kind == "config5", shapes, log)
+        # config 5: as many pairs as ONE rank of an 8-GPU job owns (8128 / 8 = 1016), half of them overlapping views
+        res["parity"] = job_parity(hip, ctx, cfg, job, d_imgs, kind == "config5", shapes, log,
+                                   npairs_sample=(len(job.my_pairs) + 7) // 8 if kind == "config5" else 96)
         log(f"strong {kind}: parity of the timed job against the oracle took {time.perf_counter() - t0:.1f} s -> ok={res['parity']['ok']}")
     job.close()
     if eng._feats is not None:
@@ -265,3 +277,74 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
     del d_imgs
     torch.cuda.empty_cache()
     return res
+
+
+def rehearse(hip, ctx, cfg, kind, worlds, dev, log, c5_images=128):
+    """One-device rehearsal of the strong-scaled job: every rank's share of an N-rank job (N in ``worlds``) run one after the
+    other through ShardedJob(overlap=True, rehearsal=...) -- the code a rank runs at N > 1 -- with each phase timed, and the
+    union of the ranks' results compared with the single-rank job (match lists by CRC, RANSAC by accepted pairs / inliers).
+    -> {"N": {"phase_ms": max over ranks per phase, "job_ms": their sum (phases are separated by barriers in the real job),
+    "per_rank_phase_ms": [...], ...}}: the share model a measured 1 -> 8 curve can be read against (`predicted` in bench.py's
+    N > 1 lines).  What it cannot contain is the xGMI part of the exchange: the peers' slices are device-to-device copies here."""
+    import zlib
+    from openpano_amd import synth
+    from openpano_amd.distributed import HipEngine, ShardedJob, shard_images
+    if kind == "config4":
+        n, H, W = 38, 867, 1300
+        allv = synth.image_set(n, H, W, seed=38, overlap=0.45, rows=2, shuffle=True)
+        d_imgs = [torch.from_numpy(v).to(dev) for v in allv]
+        inputs = [(t.data_ptr(), H, W) for t in d_imgs]
+    else:
+        n, H, W = c5_images, 3000, 4000
+        d_imgs = synth.config5_views(list(range(n)), dev)
+        inputs = [(t.data_ptr(), H, W, "u8") for t in d_imgs]
+    torch.cuda.synchronize()
+    shapes = [(W, H)] * n
+    eng = HipEngine(ctx, cfg, dev)
+    one = ShardedJob(eng, n, dev)
+    one.sift(hip.SiftCall(ctx, cfg, inputs)); one.exchange(); one.match()
+    want = {p: zlib.crc32(np.ascontiguousarray(m).tobytes()) for p, m in zip(one.my_pairs, one.lists)}
+    want_r = one.ransac_summary(shapes, 1)
+    table = (one.desc.clone(), one.coor.clone(), list(one.counts))
+    ktot = sum(table[2])
+    one.close()
+    out = {}
+    for world in worlds:
+        per_rank, seen, tot = [], {}, [0, 0]
+        for rank in range(world):
+            ids = shard_images(n, rank, world)
+            job = ShardedJob(eng, n, dev, overlap=True, rehearsal=(rank, world, table))
+            call = hip.SiftCall(ctx, cfg, [inputs[g] for g in ids]) if ids else []
+            best = None
+            for rep in range(3):                       # the third pass is the one kept: buffers at their steady size class
+                ph = {}
+
+                def lap(name, fn):
+                    torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); ph[name] = (time.perf_counter() - t) * 1e3
+                    return r
+                lap("sift", lambda: job.sift(call))
+                lap("feature all-gather", job.exchange)
+                lap("match", job.match)
+                okr = lap("ransac", lambda: job.ransac_summary(shapes, 1))
+                best = ph
+            for p, m in zip(job.my_pairs, job.lists):
+                assert p not in seen, (world, rank, p)
+                seen[p] = zlib.crc32(np.ascontiguousarray(m).tobytes())
+            tot[0] += okr[0]; tot[1] += okr[1]
+            per_rank.append({k: round(v, 4) for k, v in best.items()} | {"images": len(ids), "pairs": len(job.my_pairs), "own_pairs": len(job.local_sel)})
+            job.close()
+        assert seen == want, f"rehearsal world {world}: match lists differ from the single-rank job"
+        assert tuple(tot) == tuple(want_r), (world, tot, want_r)
+        phm = {k: max(r[k] for r in per_rank) for k in ("sift", "feature all-gather", "match", "ransac")}
+        job_ms = sum(phm.values())
+        out[str(world)] = {"phase_ms": {k: round(v, 4) for k, v in phm.items()}, "job_ms": round(job_ms, 4), "per_rank_phase_ms": per_rank,
+                           "keypoints_per_s": ktot / (phm["sift"] * 1e-3), "image_pairs_per_s": len(want) / ((phm["feature all-gather"] + phm["match"]) * 1e-3 if world > 1 else phm["match"] * 1e-3),
+                           "ransac_image_pairs_per_s": len(want) / (phm["ransac"] * 1e-3), "equals_single_rank_job": True}
+        log(f"rehearsal {kind} N={world}: phases {out[str(world)]['phase_ms']} job {job_ms:.3f} ms")
+    if eng._feats is not None:
+        eng._feats.free(); eng._feats = None
+    del d_imgs
+    torch.cuda.empty_cache()
+    return {"kind": kind, "images": n, "descriptors": int(ktot), "image_pairs": len(want), "accepted_pairs": int(want_r[0]), "inliers": int(want_r[1]),
+            "note": "every rank's share run one after the other on ONE device through ShardedJob(overlap=True, rehearsal=...); phase time of an N-rank job = max over its ranks; "
+                    "the exchange's remote part (xGMI) is a device-to-device copy here", "worlds": out}

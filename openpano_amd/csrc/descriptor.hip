@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 					}
 				}
 				const unsigned long long mask = __ballot(ok);
-				if (ok) S.q[(qhead + qn + rank_below(mask)) & (QCAP - 1)] = (unsigned)(xx + 128) | ((unsigned)(yy + 128) << 8);
+				if (ok) S.q[(qhead + qn + rank_below(mask)) & (QCAP - 1)] = (unsigned)(xx + 32768) | ((unsigned)(yy + 32768) << 16);   // 16 + 16 bits: any window radius
 				qn += __popcll(mask);
 				run = qn >= 64 || (i0 + 64 >= ncand && qn > 0);
 				if (run) {
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 					const int n = qn < 64 ? qn : 64;
 					const unsigned pk = S.q[(qhead + lane) & (QCAP - 1)];
 					cand = lane < n;
-					xx = (int)(pk & 0xFFu) - 128; yy = (int)((pk >> 8) & 0xFFu) - 128;
+					xx = (int)(pk & 0xFFFFu) - 32768; yy = (int)(pk >> 16) - 32768;
 					qhead = (qhead + n) & (QCAP - 1); qn -= n;
 					WAVE_FENCE();
 				}

@@ -391,11 +391,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 		STAMP(2);
 		if (t + 1 < ntiles) commit_tile(buf ^ 1);
 		STAMP(3);
-		__syncthreads();                              // (carries the wait for this wavefront's DMA pieces of tile t + 1)
+		// this wavefront's DMA pieces of tile t + 1 must have LANDED before the barrier releases the other wavefronts onto
+		// them.  A workgroup-scope fence only implies lgkmcnt on gfx9; the compiler happened to place vmcnt(1) here (the
+		// DMAs are older than the |y|^2 load) -- an artefact of instruction order, so the wait is spelled out.  Every
+		// load it covers was issued a whole MFMA chain ago.
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
 		STAMP(4);
 	};
 	fetch_tile(0, s_y0);
 	commit_tile(0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	for (int t = 0; t < ntiles; t += 2) {
 		tile_step(t, s_y0, s_y1, 0);

@@ -167,6 +167,10 @@ def allgatherv_features(local_desc: torch.Tensor, local_coor: torch.Tensor, loca
         return gdesc, gcoor, counts, works
     for w in works:
         w.wait()
+    if gdesc.is_cuda:
+        # wait() orders torch's current stream behind the receives (and the own-slice copy runs on it); the consumers
+        # are library calls on another stream: make the table valid for every stream before handing it out
+        torch.cuda.current_stream(gdesc.device).synchronize()
     return gdesc, gcoor, counts
 
 
@@ -289,7 +293,7 @@ class ShardedJob:
     travel, and only then the exchange is waited for -- ``exchange()`` returns with the local pairs already matched,
     ``match()`` adds the rest.  Same pair list per job, same results per pair."""
 
-    def __init__(self, engine, n_images: int, device, group=None, overlap=False):
+    def __init__(self, engine, n_images: int, device, group=None, overlap=False, rehearsal=None):
         self.e = engine
         self.n = n_images
         self.device = device
@@ -297,6 +301,14 @@ class ShardedJob:
         self.dist = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.dist else 0
         self.world = dist.get_world_size(group) if self.dist else 1
+        # ``rehearsal=(rank, world, (desc, coor, counts))``: ONE rank of a ``world``-rank job run on its own, without a
+        # process group -- the slices of the other ranks are copied out of the given whole-job table (device-to-device copies
+        # standing in for the xGMI transfers) instead of being received.  Everything else is the code a rank runs at
+        # N > 1: block ownership, own-pairs-first deal, local match during the exchange, global seeds.  Used to run all
+        # ranks' shares of a job one after the other on a single device (tests/test_gpu_multi.py, bench_match.rehearse).
+        self.rehearsal = rehearsal
+        if rehearsal is not None:
+            self.rank, self.world, self.dist = int(rehearsal[0]), int(rehearsal[1]), False
         self.local_ids = shard_images(n_images, self.rank, self.world)
         self.overlap = bool(overlap)
         self.tab = None; self.mh = None
@@ -332,7 +344,19 @@ class ShardedJob:
         self._free_results()
         self._keep = None
         works = []
-        if self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the header collective really runs
+        if self.rehearsal is not None:
+            wdesc, wcoor, gcounts = self.rehearsal[2]
+            gcounts = list(gcounts)
+            gdesc = torch.empty_like(wdesc); gcoor = torch.empty_like(wcoor)
+            lo = sum(gcounts[: self.local_ids[0]]) if self.local_ids else 0
+            hi = lo + sum(self.counts)
+            assert [gcounts[g] for g in self.local_ids] == list(self.counts), "rehearsal: this rank's SIFT output differs from the whole-job table"
+            if hi > lo:
+                gdesc[lo:hi].copy_(self.desc); gcoor[lo:hi].copy_(self.coor)          # own slice, as allgatherv_features does
+            torch.cuda.current_stream(gdesc.device).synchronize() if gdesc.is_cuda else None
+            # the peers' slices "arrive" after the own pairs have been matched (overlap) -- see below
+            self._rehearsal_fill = (wdesc, wcoor, lo, hi)
+        elif self.dist:                       # also with ONE rank (OPENPANO_FORCE_DIST): the header collective really runs
             # slices arrive in place, in GLOBAL image order: pair (i, j), its match list and its RANSAC draw
             # sequence are those of the single-rank job whatever the world size
             if self.overlap:
@@ -353,8 +377,19 @@ class ShardedJob:
             self.local_tab = self.e.table(self.desc, self.coor, self.counts)
             self.local_pairs = [(self.my_pairs[k][0] - first, self.my_pairs[k][1] - first) for k in self.local_sel]
             self.local_mh, self.local_lists = self.e.match(self.local_tab, self.local_pairs)
+        if self.rehearsal is not None:
+            wdesc, wcoor, lo, hi = self._rehearsal_fill
+            gdesc[:lo].copy_(wdesc[:lo]); gdesc[hi:].copy_(wdesc[hi:])
+            gcoor[:lo].copy_(wcoor[:lo]); gcoor[hi:].copy_(wcoor[hi:])
+            if gdesc.is_cuda:
+                torch.cuda.current_stream(gdesc.device).synchronize()
+            self._rehearsal_fill = None
         for w in works:
             w.wait()
+        if works and gdesc.is_cuda:
+            # w.wait() only makes torch's CURRENT stream wait for the NCCL receives; the library adopts the table and
+            # matches on its own context stream, which nothing orders behind them: wait on the host for the receives
+            torch.cuda.current_stream(gdesc.device).synchronize()
         self.tab = self.e.table(gdesc, gcoor, gcounts)
         return sum(gcounts)
 

@@ -22,7 +22,12 @@
 // Error behaviour follows the reference: unrecoverable conditions end in error_exit()
 // (lib/debugutils.cc:57-60: message on stderr, exit(1)); no exception crosses the C-ABI.
 #pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <memory>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -200,25 +205,43 @@ class HipSIFTDetector PANO_DETECTOR_BASE {
 			// Images that came out of a decoder are bytes / 255 (read_img, lib/imgio.cc:54-56,75-77: (float)((double)byte / 255.0)).
 			// When EVERY value of every image is exactly such a float, the bytes travel instead -- a quarter of the PCIe traffic,
 			// pageable memory at that -- and the device converts them with the same expression (OP_U8): the same features, bit for bit.
-			std::vector<std::vector<unsigned char>> bytes(imgs.size());
+			// Non-decoder inputs (warped, normalised images) must not pay for this: a probe of every image's first values decides
+			// whether the byte buffers are allocated at all, the full scan stops at the first chunk that holds a mismatch, and
+			// the comparison is on BIT PATTERNS (-0.0f is not the float of byte 0).
+			std::vector<std::unique_ptr<unsigned char[]>> bytes(imgs.size());
 			if (!HipContext::group()) {
-				int all_bytes = 1;
-				for (size_t k = 0; k < imgs.size(); ++k) bytes[k].resize((size_t)imgs[k]->rows() * imgs[k]->cols() * 3);
-#pragma omp parallel for schedule(dynamic) reduction(&: all_bytes)
-				for (long job = 0; job < (long)imgs.size() * 8; ++job) {
-					const size_t k = (size_t)(job >> 3), part = (size_t)(job & 7), n = bytes[k].size();
+				auto as_byte = [](float v, unsigned char& b) {
+					const float q = v * 255.f + 0.5f;
+					const int c = q >= 0.f && q < 256.f ? (int)q : 0;
+					b = (unsigned char)c;
+					const float back = (float)((double)c / 255.0);
+					uint32_t x, y; memcpy(&x, &back, 4); memcpy(&y, &v, 4);
+					return x == y;
+				};
+				bool plausible = true;
+				for (size_t k = 0; k < imgs.size() && plausible; ++k) {
+					const size_t n = std::min<size_t>((size_t)imgs[k]->rows() * imgs[k]->cols() * 3, 4096);
 					const float* v = imgs[k]->ptr();
-					unsigned char* b = bytes[k].data();
-					int ok = 1;
-					for (size_t e = n * part / 8; e < n * (part + 1) / 8; ++e) {
-						const float q = v[e] * 255.f + 0.5f;
-						const int c = q >= 0.f && q < 256.f ? (int)q : 0;
-						ok &= ((float)((double)c / 255.0) == v[e]);
-						b[e] = (unsigned char)c;
-					}
-					all_bytes &= ok;
+					unsigned char b;
+					for (size_t e = 0; e < n && plausible; ++e) plausible = as_byte(v[e], b);
 				}
-				if (all_bytes) for (size_t k = 0; k < imgs.size(); ++k) { ims[k].data = bytes[k].data(); ims[k].dtype = OP_U8; }
+				std::atomic<int> all_bytes{plausible ? 1 : 0};
+				if (plausible) {
+					for (size_t k = 0; k < imgs.size(); ++k) bytes[k].reset(new unsigned char[(size_t)imgs[k]->rows() * imgs[k]->cols() * 3]);
+#pragma omp parallel for schedule(dynamic)
+					for (long job = 0; job < (long)imgs.size() * 8; ++job) {
+						const size_t k = (size_t)(job >> 3), part = (size_t)(job & 7), n = (size_t)imgs[k]->rows() * imgs[k]->cols() * 3;
+						const float* v = imgs[k]->ptr();
+						unsigned char* b = bytes[k].get();
+						const size_t e1 = n * (part + 1) / 8;
+						for (size_t e0 = n * part / 8; e0 < e1 && all_bytes.load(std::memory_order_relaxed); e0 += 65536) {
+							bool ok = true;
+							for (size_t e = e0; e < std::min(e1, e0 + 65536); ++e) ok &= as_byte(v[e], b[e]);
+							if (!ok) all_bytes.store(0, std::memory_order_relaxed);
+						}
+					}
+				}
+				if (all_bytes.load()) for (size_t k = 0; k < imgs.size(); ++k) { ims[k].data = bytes[k].get(); ims[k].dtype = OP_U8; }
 			}
 			if (op_group* g = HipContext::group()) {        // images dealt over the group's GPUs, features all-gathered
 				PANO_HIP_CHECK(op_sift_batch_multi(g, &cfg, ims.data(), (int)ims.size(), &fs.handle));

@@ -295,6 +295,33 @@ int ref_ransac(const int* match, int m, const double* kp1, int nk1, const double
 	return ok ? 1 : 0;
 }
 
+// The RANSAC half of the pair loop of Stitcher::pairwise_match (stitch/stitcher.cc:100-113: one TransformEstimation per
+// matched pair inside `omp parallel for schedule(dynamic)`) over GIVEN match lists on the host cores -- the CPU baseline of
+// op_ransac_pairs (bench.py).  match: the pairs' <first, second> lists back to back (mcount[p] entries each); coor: the
+// images' keypoint coordinates back to back (kcount[i] points each).  Every estimation draws from the same injected seed
+// (the seam above is one global): this entry is for timing, not for parity.  Returns the number of accepted pairs.
+long ref_ransac_pairs_batch(const int* match, const int* mcount, int npairs, const int* pairs, const double* coor, const int* kcount, int n,
+		const int* shapes_wh, int nthreads, unsigned seed, long* inliers_total) {
+	std::vector<std::vector<Vec2D>> kp(n);
+	size_t off = 0;
+	for (int i = 0; i < n; ++i) { for (int k = 0; k < kcount[i]; ++k, ++off) kp[i].emplace_back(coor[2 * off], coor[2 * off + 1]); }
+	std::vector<MatchData> md(npairs);
+	size_t at = 0;
+	for (int p = 0; p < npairs; ++p) for (int k = 0; k < mcount[p]; ++k, ++at) md[p].data.emplace_back(match[2 * at], match[2 * at + 1]);
+	g_ref_seed = seed;
+	omp_set_num_threads(nthreads);
+	long ok = 0, inl = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+:ok, inl)
+	for (int p = 0; p < npairs; ++p) {
+		const int i = pairs[2 * p], j = pairs[2 * p + 1];
+		MatchInfo info;
+		TransformEstimation te(md[p], kp[i], kp[j], Shape2D(shapes_wh[2 * i], shapes_wh[2 * i + 1]), Shape2D(shapes_wh[2 * j], shapes_wh[2 * j + 1]));
+		if (te.get_transform(&info)) { ++ok; inl += (long)info.match.size(); }
+	}
+	if (inliers_total) *inliers_total = inl;
+	return ok;
+}
+
 // CameraEstimator{pairwise_matches, shapes}.estimate() (stitch/camera_estimator.cc:31-103, the
 // body of Stitcher::estimate_camera, stitcher.cc:146-158) on a given pairwise MatchInfo table.
 // entries: np directed entries (i, j) -> pairwise_matches[i][j] = {conf, homo, pts}; pts rows are
@@ -404,6 +431,7 @@ struct BlendRun {
 	ConnectedImages bundle;
 	Mat32f result;
 	Vec2D resolution;
+	double blend_seconds = 0;      // wall time of ConnectedImages::blend() alone (bench.py's CPU baseline of op_blend)
 };
 void* ref_blend_new(int proj_method, int identity_idx, int n, const float* const* rgb, const int* hw, const double* homo) {
 	BlendRun* r = new BlendRun;
@@ -420,9 +448,12 @@ void* ref_blend_new(int proj_method, int identity_idx, int n, const float* const
 	r->bundle.calc_inverse_homo();
 	r->bundle.update_proj_range();
 	r->resolution = r->bundle.get_final_resolution();
+	const double t0 = omp_get_wtime();
 	r->result = r->bundle.blend();
+	r->blend_seconds = omp_get_wtime() - t0;
 	return r;
 }
+double ref_blend_seconds(void* hd) { return ((BlendRun*)hd)->blend_seconds; }
 void ref_blend_dims(void* hd, int* h, int* w) { BlendRun* r = (BlendRun*)hd; *h = r->result.height(); *w = r->result.width(); }
 void ref_blend_get(void* hd, float* out) {
 	BlendRun* r = (BlendRun*)hd;

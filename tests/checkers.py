@@ -430,6 +430,41 @@ class Ref(_StagedBase):
         for k, v in kv.items():
             assert self.lib.ref_config_set(k.encode(), float(np.float32(v))) == 0, k
 
+    def ransac_pairs_batch(self, lists, pairs, coors, shapes_wh, nthreads, seed=1):
+        """The RANSAC half of Stitcher::pairwise_match's pair loop (OpenMP over pairs) on given match lists: timing entry.
+        lists[p]: (m, 2) int32; coors[i]: (K_i, 2) float64; shapes_wh: (n, 2).  -> (accepted pairs, total inliers)"""
+        lib = self.lib
+        lib.ref_ransac_pairs_batch.restype = C.c_long
+        lib.ref_ransac_pairs_batch.argtypes = [_i32p, _i32p, C.c_int, _i32p, _f64p, _i32p, C.c_int, _i32p, C.c_int, C.c_uint, C.POINTER(C.c_long)]
+        mc = np.array([len(m) for m in lists], np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(m, np.int32).reshape(-1, 2) for m in lists] + [np.zeros((1, 2), np.int32)]))
+        kc = np.array([len(c) for c in coors], np.int32)
+        co = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64).reshape(-1, 2) for c in coors] + [np.zeros((1, 2))]))
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+        sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+        inl = C.c_long()
+        ok = lib.ref_ransac_pairs_batch(flat.reshape(-1), mc, len(mc), pr.reshape(-1), co.reshape(-1), kc, len(kc), sh.reshape(-1),
+                                        int(nthreads), int(seed), C.byref(inl))
+        return int(ok), int(inl.value)
+
+    def blend_timed(self, imgs, homos, proj_method, identity_idx, nthreads):
+        """ConnectedImages::blend (its own OpenMP loops, nthreads) -> (canvas h, w, seconds inside blend() alone)"""
+        self._bind_blend()
+        self.lib.ref_blend_seconds.restype = C.c_double
+        self.lib.ref_blend_seconds.argtypes = [C.c_void_p]
+        self.lib.ref_set_threads(int(nthreads))
+        n = len(imgs)
+        ptrs = (C.POINTER(C.c_float) * n)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in imgs])
+        hw = np.array([[im.shape[0], im.shape[1]] for im in imgs], np.int32)
+        homo = np.ascontiguousarray(np.asarray(homos, np.float64).reshape(n, 9))
+        hd = self.lib.ref_blend_new(int(proj_method), int(identity_idx), n, ptrs, hw.reshape(-1), homo.reshape(-1))
+        h, w = C.c_int(), C.c_int()
+        self.lib.ref_blend_dims(hd, C.byref(h), C.byref(w))
+        t = float(self.lib.ref_blend_seconds(hd))
+        self.lib.ref_blend_free(hd)
+        self.lib.ref_set_threads(1)
+        return h.value, w.value, t
+
     def ransac(self, match, kp1, kp2, shape1, shape2, seed):
         match = np.ascontiguousarray(match, np.int32).reshape(-1, 2)
         kp1 = np.ascontiguousarray(kp1, np.float64).reshape(-1, 2); kp2 = np.ascontiguousarray(kp2, np.float64).reshape(-1, 2)

@@ -105,3 +105,25 @@ def test_pmc_evidence_belongs_to_the_built_library():
     assert want, "pmc_latest.json has no _meta.lib_sha256_16"
     if want != got:
         pytest.skip(f"PMC counters were collected on library {want}, the built library is {got}: roofline.traffic will be null until the PMC passes are re-run")
+
+
+def test_full_job_record_belongs_to_the_built_library():
+    """profiles/config5_all_pairs_latest.json is the record of the whole config-5 parity job (all 8128 match sets and RANSAC
+    results against the oracle, OPENPANO_FULL_C5=1 tests/test_gpu_fullsize.py -k whole_match_job), written by the test
+    itself together with the hash of the library it ran on.  A record of another build proves nothing about this one:
+    reported as STALE (a skip -- the job needs a GPU and ~7 minutes, it cannot be re-run here)."""
+    import hashlib
+    import json
+    import pytest
+    lib = os.path.join(ROOT, "openpano_amd", "libopenpano_hip.so")
+    recp = os.path.join(ROOT, "profiles", "config5_all_pairs_latest.json")
+    if not os.path.exists(recp):
+        pytest.skip("no full-job record committed")
+    rec = json.load(open(recp))
+    assert rec["full"] and rec["match_pairs_checked"] == rec["pairs_in_job"] == 8128 and rec["ransac_pairs_checked"] == 8128
+    assert rec["match_pairs_differing"] == 0 and rec["images"] == 128
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    got = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    if rec["lib_sha256_16"] != got:
+        pytest.skip(f"STALE: the full config-5 parity job ran on library {rec['lib_sha256_16']}, the built library is {got}")

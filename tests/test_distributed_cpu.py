@@ -191,3 +191,41 @@ def test_more_ranks_than_images():
     assert all(r[5] == res[0][5] for r in res) and sorted(res[0][5]) == sorted(single[4])
     for p in single[4]:
         assert res[0][5][p][0] == single[4][p][0]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rehearsal_mode_equals_single_rank(world):
+    """ShardedJob(rehearsal=(rank, world, table)): every rank of a world-N job run one after the other in ONE process
+    (no process group; the peers' slices are copied out of the whole-job table).  It is the code path bench_match.rehearse
+    and tests/test_gpu_multi.py use to run all N = 2, 4, 8 shares of a job on a single device: block ownership, own pairs
+    first, global seeds -- the union of the ranks' results must be the single-rank job, pair for pair.  World 8 over 5
+    images leaves three ranks without an image."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from openpano_amd.config import PanoConfig
+    from openpano_amd.distributed import ShardedJob, all_pairs, shard_images
+    views = _job_views()
+    n = len(views)
+    shapes = [(280, 200)] * n
+    eng = OracleEngine(PanoConfig())
+    one = ShardedJob(eng, n, torch.device("cpu"))
+    one.sift(views); one.exchange(); one.match(); one.ransac(shapes, base_seed=9)
+    want = {p: (m.tolist(), r) for p, m, r in zip(one.my_pairs, one.lists, one.rres)}
+    table = (one.desc.clone(), one.coor.clone(), list(one.counts))
+    seen = set()
+    for rank in range(world):
+        job = ShardedJob(eng, n, torch.device("cpu"), overlap=True, rehearsal=(rank, world, table))
+        assert job.local_ids == shard_images(n, rank, world) and not job.dist
+        job.sift([views[g] for g in job.local_ids])
+        assert job.exchange() == sum(table[2])
+        assert torch.equal(job._keep[0], table[0]) and torch.equal(job._keep[1], table[1])
+        job.match(); job.ransac(shapes, base_seed=9)
+        for p, m, r in zip(job.my_pairs, job.lists, job.rres):
+            assert p not in seen
+            seen.add(p)
+            assert m.tolist() == want[p][0], (rank, p)
+            w = want[p][1]
+            assert r["ok"] == w["ok"] and r["best_hyp"] == w["best_hyp"] and r["confidence"] == w["confidence"], (rank, p)
+            assert np.array_equal(r["inliers"], w["inliers"]) and np.array_equal(r["homo"], w["homo"], equal_nan=True), (rank, p)
+        job.close()
+    assert sorted(seen) == all_pairs(n)

@@ -206,6 +206,7 @@ def test_config5_whole_match_job_digest(ctx, oracle, cfg):
         # get_transform under the same injected seeds, from the match lists that never left the device
         nok = _ransac_job(ctx, oracle, cfg, f, pairs, mh, got, coors, [(4000, 3000)] * n)
         assert nok > 300, nok
+    nok = nok if full else None
     mh.free()
     f.free()
     if full:
@@ -219,3 +220,19 @@ def test_config5_whole_match_job_digest(ctx, oracle, cfg):
     bad = [(pairs[k], len(got[k]), int(c)) for k, c, d in zip(sel, cnt, dig)
            if len(got[k]) != c or oracle.match_digest(got[k]) != int(d)]
     assert not bad, bad[:10]
+    # the record of this run, tied to the library that produced it: tests/test_bench_contract.py compares the hash with the built
+    # library and reports the committed copy (profiles/config5_all_pairs_latest.json) as STALE when kernels changed after it
+    import hashlib
+    import json
+    import time
+    rec = {"lib_sha256_16": hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16], "full": full, "images": n,
+           "descriptors": int(sum(len(d) for d in descs)), "pairs_in_job": len(pairs), "match_pairs_checked": len(sel),
+           "matches_checked": int(cnt.sum()), "match_pairs_differing": len(bad),
+           "ransac_pairs_checked": len(pairs) if full else 0, "ransac_accepted_pairs": int(nok) if full else None,
+           "checked_against": "oracle/ (exact FeatureMatcher restatement: count + order-free digest per pair; TransformEstimation restatement under the "
+                              "job's injected seeds: winner, inlier set, acceptance, confidence, homography), itself pinned to oracle/_ref",
+           "test": "tests/test_gpu_fullsize.py::test_config5_whole_match_job_digest", "unix_time": int(time.time())}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "config5_all_pairs.json" if full else "config5_sampled_pairs.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)

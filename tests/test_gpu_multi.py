@@ -140,3 +140,30 @@ def test_sharded_job_overlap_path_on_the_device(cfg, monkeypatch, world):
     assert sorted(seen) == D.all_pairs(n)
     assert (tot_ok, tot_inl) == (ok1, inl1) and ok1 >= 3
     ctx.close()
+
+
+def test_rehearsal_of_2_4_8_rank_jobs_on_one_device(cfg):
+    """bench_match.rehearse: all ranks' shares of the N = 2, 4, 8 strong-scaled jobs, one after the other on this device, through
+    ShardedJob(overlap=True, rehearsal=...) with the product engine -- a config-5-shaped job (32 of the 128 4000x3000 uint8 images,
+    496 pairs; scripts/scale_rehearsal.py runs config 4 and the whole config 5 the same way and its record is what bench.py --gpus N
+    prints as `predicted`).  rehearse() itself asserts that the union of every world's results is the single-rank job (match
+    lists by CRC, RANSAC accepted pairs and inliers); here: every world ran, the shares add up, and the per-rank SIFT share
+    shrinks with N."""
+    import sys
+    import torch
+    from openpano_amd import hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_match import rehearse
+    dev = torch.device("cuda", 0)
+    ctx = hip.Context(0)
+    res = rehearse(hip, ctx, cfg, "config5", (1, 2, 4, 8), dev, lambda m: None, c5_images=32)
+    ctx.close()
+    assert res["image_pairs"] == 496 and res["descriptors"] > 32 * 2500 and res["accepted_pairs"] >= 28
+    for world in (1, 2, 4, 8):
+        w = res["worlds"][str(world)]
+        assert w["equals_single_rank_job"] and len(w["per_rank_phase_ms"]) == world
+        assert sum(r["pairs"] for r in w["per_rank_phase_ms"]) == 496 and sum(r["images"] for r in w["per_rank_phase_ms"]) == 32
+        if world > 1:                      # own pairs first: C(32 / world, 2) per rank
+            k = 32 // world
+            assert all(r["own_pairs"] == k * (k - 1) // 2 for r in w["per_rank_phase_ms"])
+    assert res["worlds"]["8"]["phase_ms"]["sift"] < res["worlds"]["1"]["phase_ms"]["sift"]
