@@ -41,32 +41,14 @@ def run_pipeline(hip, ctx, cfg, views, pairs, log, note=None):
         st["sift"] = time.perf_counter() - t; t = time.perf_counter()
         mh = hip.match_pairs_handle(ctx, cfg, feats, pairs)
         st["match"] = time.perf_counter() - t; t = time.perf_counter()
-        rs = hip.ransac_pairs(ctx, cfg, feats, mh, pairs, shapes, base_seed=42)
-        st["ransac"] = time.perf_counter() - t; t = time.perf_counter()
-        # Stitcher::match_image's bookkeeping (stitcher.cc:79-93): both directions of every connected pair
-        coors = {}
-        ij, conf, homo, cnt, pts = [], [], [], [], []
-        for p, (i, j) in enumerate(pairs):
-            r = rs[p]
-            if not r["ok"]:
-                continue
-            for k in (i, j):
-                if k not in coors:
-                    coors[k] = feats.get(k)[1]
-            m = mh.get(p)
-            inl = r["inliers"]
-            a = coors[i][m[inl, 0]]; b = coors[j][m[inl, 1]]
-            hinv = np.zeros(9); host.pano_homography_inverse(np.ascontiguousarray(r["homo"].reshape(9)), hinv)
-            hinv = hinv / hinv[8]
-            ij += [[i, j], [j, i]]; conf += [r["confidence"]] * 2; homo += [r["homo"].reshape(9), hinv]
-            cnt += [len(inl)] * 2; pts += [np.concatenate([a, b], 1), np.concatenate([b, a], 1)]
-        st["pairwise table (host glue)"] = time.perf_counter() - t; t = time.perf_counter()
-        res = dict(connected_pairs=len(ij) // 2, inlier_matches=int(sum(cnt) // 2), descriptors=int(feats.total))
-        if ij:
+        # RANSAC of every pair + Stitcher::match_image's bookkeeping (stitcher.cc:79-93: both directions of every connected
+        # pair) inside the library: op_ransac_pairs + op_pairwise_table hand over CameraEstimator's input as flat arrays
+        ij, conf, homo, cnt, pts, nconn = hip.ransac_pairwise_table(ctx, cfg, feats, mh, pairs, shapes, base_seed=42)
+        st["ransac + pairwise table"] = time.perf_counter() - t; t = time.perf_counter()
+        res = dict(connected_pairs=int(nconn), inlier_matches=int(cnt.sum() // 2), descriptors=int(feats.total))
+        if len(ij):
             cams = np.zeros((n, 13))
-            host.pano_estimate_cameras(n, shapes.reshape(-1).copy(), len(ij), np.asarray(ij, np.int32).reshape(-1), np.asarray(conf, np.float32),
-                                       np.ascontiguousarray(np.stack(homo)).reshape(-1), np.asarray(cnt, np.int32),
-                                       np.ascontiguousarray(np.concatenate(pts)).reshape(-1), cams.reshape(-1))
+            host.pano_estimate_cameras(n, shapes.reshape(-1).copy(), len(ij), ij.reshape(-1), conf, homo.reshape(-1), cnt, pts.reshape(-1), cams.reshape(-1))
             st["camera estimation + bundle adjustment (host)"] = time.perf_counter() - t; t = time.perf_counter()
             homos = []
             for k in range(n):

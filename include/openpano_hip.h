@@ -269,6 +269,18 @@ int op_ransac_best(const op_ransac_result* r, int p, int* hyp, int* count);
 int op_ransac_summary(const op_ransac_result* r, int* accepted_pairs, int64_t* inliers);
 void op_ransac_free(op_ransac_result* r);
 
+/* Stitcher::match_image's bookkeeping for a whole job (stitch/stitcher.cc:79-93): every ACCEPTED pair (i, j) of the result
+ * becomes two directed entries -- pairwise_matches[i][j] = MatchInfo{confidence, homo (j -> i), matches (point in i, point
+ * in j)} and pairwise_matches[j][i] = the same with homo.inverse() scaled by 1 / inv[8] and every match reversed
+ * (match_info.hh:21-25) -- in the flat form pano_estimate_cameras (include/pano_host.h) takes: CameraEstimator's input
+ * without a pass through the caller's own containers.  `pairs` / npairs are those of the op_ransac_pairs call that made r,
+ * m the match lists it read.  Sizes first: entries = 2 x accepted pairs, points = total rows of pts.
+ *   ij      entries x 2        conf  entries        homo  entries x 9        cnt  entries
+ *   pts     points x 4 (first.x, first.y, second.x, second.y), entries back to back */
+int op_pairwise_table_size(const op_ransac_result* r, int* entries, int64_t* points);
+int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, const op_ransac_result* r, const int* pairs, int npairs,
+		int* ij, float* conf, double* homo, int* cnt, double* pts);
+
 /* =====================================================================================
  * WARP + BLEND -- replaces ConnectedImages::blend() (stitch/stitcher_image.hh:92,
  * stitch/stitcher_image.cc:116-155) together with the blender it constructs:

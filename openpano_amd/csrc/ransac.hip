@@ -805,4 +805,58 @@ int op_ransac_summary(const op_ransac_result* r, int* accepted_pairs, int64_t* i
 }
 void op_ransac_free(op_ransac_result* r) { delete r; }
 
+// ---- Stitcher::match_image's bookkeeping for the whole job (stitch/stitcher.cc:79-93) ----
+// Every accepted pair (i, j) fills pairwise_matches[i][j] = info and pairwise_matches[j][i] = the same with the inverse
+// homography scaled by 1 / inv[8] and every match reversed (match_info.hh:21-25).  The table comes out in the flat form
+// pano_estimate_cameras (include/pano_host.h) takes: per directed entry (i, j): confidence, homo (j -> i), the number of
+// inlier matches and the matched points (point in i, point in j) back to back.
+int op_pairwise_table_size(const op_ransac_result* r, int* entries, int64_t* points) {
+	if (!r || !entries || !points) OP_FAIL(OP_ERR_INVALID, "op_pairwise_table_size: bad argument");
+	int e = 0; int64_t pt = 0;
+	for (auto& it : r->items) if (it.ok) { e += 2; pt += 2 * (int64_t)it.inliers.size(); }
+	*entries = e; *points = pt;
+	return OP_OK;
+}
+int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, const op_ransac_result* r, const int* pairs, int npairs,
+		int* ij, float* conf, double* homo, int* cnt, double* pts) {
+	if (!ctx || !f || !m || !r || !pairs || npairs != (int)r->items.size() || npairs != op_matches_num_pairs(m) || !ij || !conf || !homo || !cnt || !pts)
+		OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: bad argument");
+	const FeatView fv = op_features_view(f);
+	const double* coor = op_features_coor_host(f, ctx);
+	const int* lists = op_matches_host(m);
+	if (!coor || !lists) return OP_ERR_HIP;
+	const std::vector<int64_t>& moff = op_matches_offsets(m);
+	const std::vector<int>& mcnt = op_matches_counts(m);
+	int e = 0; int64_t at = 0;
+	for (int p = 0; p < npairs; ++p) {
+		const op_ransac_result::Item& it = r->items[p];
+		if (!it.ok) continue;
+		const int i = pairs[2 * p], j = pairs[2 * p + 1];
+		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: image index out of range");
+		double h[9], inv[9];
+		std::memcpy(h, it.homo, sizeof(h));
+		if (!inverse3(h, inv)) OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: accepted homography is singular");   // cannot happen: the acceptance epilogue inverted it
+		const double s = 1.0 / inv[8];                                                   // inv.mult(1.0 / inv[8]), stitcher.cc:80
+		for (int k = 0; k < 9; ++k) inv[k] *= s;
+		const int ni = (int)it.inliers.size();
+		const double* ki = coor + fv.offsets[i] * 2; const double* kj = coor + fv.offsets[j] * 2;
+		const int* lp = lists + 2 * moff[p];
+		ij[2 * e] = i; ij[2 * e + 1] = j; ij[2 * e + 2] = j; ij[2 * e + 3] = i;
+		conf[e] = it.confidence; conf[e + 1] = it.confidence;
+		std::memcpy(homo + 9 * (size_t)e, h, sizeof(h)); std::memcpy(homo + 9 * (size_t)(e + 1), inv, sizeof(inv));
+		cnt[e] = ni; cnt[e + 1] = ni;
+		double* a = pts + 4 * at; double* b = a + 4 * (size_t)ni;
+		for (int q = 0; q < ni; ++q) {
+			const int k = it.inliers[q];
+			if (k < 0 || k >= mcnt[p]) OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: inlier index outside the pair's match list");
+			const int fi = lp[2 * k], se = lp[2 * k + 1];
+			if (fi < 0 || se < 0 || fi >= fv.counts[i] || se >= fv.counts[j]) OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: match index outside the image's keypoints");
+			a[4 * q] = ki[2 * fi]; a[4 * q + 1] = ki[2 * fi + 1]; a[4 * q + 2] = kj[2 * se]; a[4 * q + 3] = kj[2 * se + 1];
+			b[4 * q] = kj[2 * se]; b[4 * q + 1] = kj[2 * se + 1]; b[4 * q + 2] = ki[2 * fi]; b[4 * q + 3] = ki[2 * fi + 1];
+		}
+		at += 2 * (int64_t)ni; e += 2;
+	}
+	return OP_OK;
+}
+
 }	// extern "C"

@@ -181,6 +181,10 @@ def lib():
     if hasattr(L, "op_ransac_summary"):
         L.op_ransac_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.op_ransac_free.argtypes = [C.c_void_p]
+    if hasattr(L, "op_pairwise_table"):
+        L.op_pairwise_table_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.op_pairwise_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.op_blend_prepare.argtypes = [C.POINTER(OpConfig), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.POINTER(OpBlendGeom), C.c_void_p, C.c_void_p]
     L.op_blend_canvas_dims.argtypes = [C.POINTER(OpBlendGeom), C.POINTER(OpBlendImage), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -665,6 +669,33 @@ def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, p
     check(L.op_ransac_summary(h, C.byref(ok), C.byref(inl)))
     L.op_ransac_free(h)
     return ok.value, inl.value
+
+
+def ransac_pairwise_table(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0, seeds=None):
+    """op_ransac_pairs + op_pairwise_table: RANSAC of every pair and Stitcher::match_image's bookkeeping (stitcher.cc:79-93)
+    without unpacking a pair into Python.  -> (ij (E, 2) int32, conf (E,) float32, homo (E, 9) float64, cnt (E,) int32,
+    pts (sum cnt, 4) float64, accepted pairs): the arguments of pano_estimate_cameras; E = 2 x accepted pairs."""
+    L = lib()
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+    sd = np.ascontiguousarray(np.asarray(seeds, np.uint32)) if seeds is not None else None
+    ccfg = OpConfig.from_config(cfg)
+    h = C.c_void_p()
+    check(L.op_ransac_pairs(ctx.handle, C.byref(ccfg), feats.handle, matches.handle, pr.ctypes.data_as(C.c_void_p), len(pr),
+                            sh.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if sd is not None else None,
+                            int(base_seed), C.byref(h)))
+    try:
+        ne = C.c_int(); npt = C.c_int64()
+        check(L.op_pairwise_table_size(h, C.byref(ne), C.byref(npt)))
+        E, P = ne.value, npt.value
+        ij = np.zeros((max(E, 1), 2), np.int32); conf = np.zeros(max(E, 1), np.float32); homo = np.zeros((max(E, 1), 9), np.float64)
+        cnt = np.zeros(max(E, 1), np.int32); pts = np.zeros((max(P, 1), 4), np.float64)
+        check(L.op_pairwise_table(ctx.handle, feats.handle, matches.handle, h, pr.ctypes.data_as(C.c_void_p), len(pr),
+                                  ij.ctypes.data_as(C.c_void_p), conf.ctypes.data_as(C.c_void_p), homo.ctypes.data_as(C.c_void_p),
+                                  cnt.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p)))
+        return ij[:E], conf[:E], homo[:E], cnt[:E], pts[:P], E // 2
+    finally:
+        L.op_ransac_free(h)
 
 
 def match_pairs(ctx: Context, cfg, feats: Features, pairs):

@@ -240,15 +240,20 @@ class IncrementalBundleAdjuster {
 			int itr = 0, nr_non_decrease = 0;
 			inlier_threshold = std::numeric_limits<int>::max();
 			const size_t idt = index_map[identity_idx];
+			// A rejected step leaves `state` as it was: the next iteration's Jacobian -- hence JtJ, its damping and its
+			// factorization -- is the one just computed; only the residuals (those of the REJECTED trial, as in the
+			// reference, :146-160) and with them J^T r changed.  `fresh` says when the state moved.  An optimize() call
+			// ends with six rejected steps in a row, so five of its ~6.6 iterations re-use the factorization.
+			bool fresh = true;
 			while (itr++ < LM_MAX_ITER) {
-				const std::vector<double> update = get_param_update(state, err_stat.residuals, config::LM_LAMBDA);
+				const std::vector<double> update = get_param_update(state, err_stat.residuals, config::LM_LAMBDA, fresh);
 				ParamState new_state;
 				new_state.params = state.get_params();
 				for (size_t i = 0; i < new_state.params.size(); ++i)
 					if (i < idt * 6 + 3 || i >= idt * 6 + 6) new_state.params[i] -= update[i];     // R of the identity image stays
 				err_stat = calcError(new_state);
-				if (err_stat.avg >= best_err - 1e-3) nr_non_decrease++;
-				else { nr_non_decrease = 0; best_err = err_stat.avg; state = std::move(new_state); }
+				if (err_stat.avg >= best_err - 1e-3) { nr_non_decrease++; fresh = false; }
+				else { nr_non_decrease = 0; best_err = err_stat.avg; state = std::move(new_state); fresh = true; }
 				if (nr_non_decrease > 5) break;
 			}
 			last_error = best_err; last_iterations = itr;
@@ -357,20 +362,26 @@ class IncrementalBundleAdjuster {
 		}
 
 		// (JtJ + damping) x = J^T r  (:231-251)
-		std::vector<double> get_param_update(const ParamState& state, const std::vector<double>& residual, float lambda) {
+		// fresh = false: `state` is the one of the previous call (a rejected step in between): JtJ, its damping and its
+		// factorization are kept, J^T r is re-accumulated from the kept derivative rows with the new residuals
+		std::vector<double> get_param_update(const ParamState& state, const std::vector<double>& residual, float lambda, bool fresh = true) {
 			const int nr_img = (int)idx_added.size(), np = nr_img * NR_PARAM_PER_CAMERA;
 			double t0 = ba_now();
-			calcJacobianSymbolic(state, residual);
+			calcJacobianSymbolic(state, residual, fresh);
 			ba_prof().t_jac += ba_now() - t0; t0 = ba_now();
-			for (int i = 0; i < np; ++i) {
-				if (i % NR_PARAM_PER_CAMERA >= 3) JtJ[(size_t)i * np + i] += lambda;
-				else JtJ[(size_t)i * np + i] += lambda / 10.f;
+			if (fresh) {
+				for (int i = 0; i < np; ++i) {
+					if (i % NR_PARAM_PER_CAMERA >= 3) JtJ[(size_t)i * np + i] += lambda;
+					else JtJ[(size_t)i * np + i] += lambda / 10.f;
+				}
+				pano_la::colpiv_qr_factor(JtJ.data(), np, qr);
 			}
 			std::vector<double> x(np, 0.0);
-			pano_la::colpiv_qr_solve(JtJ.data(), np, Jtr.data(), x.data());
+			pano_la::colpiv_qr_apply(qr, Jtr.data(), x.data());
 			ba_prof().t_solve += ba_now() - t0; ba_prof().n_iter++;
 			return x;
 		}
+		pano_la::ColPivQR qr;               // factorization of the damped JtJ of the current state
 
 		// Analytic derivatives of the residuals (Brown & Lowe, IJCV'07, section 4) -> JtJ and J^T r (:276-385)
 		//
@@ -405,9 +416,30 @@ class IncrementalBundleAdjuster {
 			topo_built = topo_gen; topo_imgs = nr_img;
 		}
 
-		void calcJacobianSymbolic(const ParamState& state, const std::vector<double>& residual) {
+		void calcJacobianSymbolic(const ParamState& state, const std::vector<double>& residual, bool fresh = true) {
 			const int nr_img = (int)idx_added.size();
 			const int np = nr_img * NR_PARAM_PER_CAMERA;
+			if (!fresh) {              // same state as the previous call: the derivative rows and JtJ stand; J^T r with the new residuals
+				const int ndiag0 = nr_img;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads()) proc_bind(close)
+				for (int c = 0; c < ndiag0; ++c) {
+					double g[6] = {0, 0, 0, 0, 0, 0};
+					for (int q : cam_pairs[c]) {
+						const MatchPair& pair = match_pairs[q];
+						const int nm = (int)pair.m.match.size();
+						const double* row = deriv.data() + (size_t)match_cnt_prefix_sum[q] * 24;
+						const double* res = residual.data() + (size_t)match_cnt_prefix_sum[q] * 2;
+						const int o = index_map[pair.from] == c ? 0 : 6;
+						for (int k = 0; k < nm; ++k, row += 24, res += 2) {
+							const double* dx = row + o; const double* dy = row + 12 + o;
+							const double rx = res[0], ry = res[1];
+							for (int a = 0; a < 6; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
+						}
+					}
+					for (int a = 0; a < 6; ++a) Jtr[c * NR_PARAM_PER_CAMERA + a] = g[a];
+				}
+				return;
+			}
 			std::fill(JtJ.begin(), JtJ.end(), 0.0);
 			std::fill(Jtr.begin(), Jtr.end(), 0.0);
 			const auto& cameras = state.get_cameras();

@@ -124,9 +124,25 @@ inline void jacobi_svd(const double* a, int m, int n, double* U, double* S, doub
 // every R_ij sees exactly the operations, in exactly the order, of the textbook column-by-column
 // form -- so the result is bit-identical to it -- but the inner loops are contiguous, carry no
 // dependence and vectorise (the column form spends its time in n^3/3 latency-bound scalar adds).
-inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x) {
-	std::vector<double> R(Ain, Ain + (size_t)n * n), tau(n, 0.0), nrm(n), nrm0(n), c(b, b + n), w(n), v(n);
-	std::vector<int> perm(n);
+// The factorization and its application are separate steps: the Levenberg-Marquardt loop of the bundle adjuster solves
+// with the SAME matrix again after every rejected step (only the right-hand side changed), and a factorization kept
+// across those solves gives the same x as factoring again -- the same operations on the same values.
+struct ColPivQR {
+	int n = 0, rank = 0;
+	std::vector<double> R, tau;       // R: upper triangle = R factor, below the diagonal the Householder vectors (v_k = 1 implied)
+	std::vector<int> perm;
+};
+// AVX-512 where the host has it (the loops below are contiguous fp64 sweeps; -ffp-contract=off, so a wider vector changes
+// no bit of any element's operation sequence)
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define PANO_LA_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define PANO_LA_CLONES
+#endif
+PANO_LA_CLONES inline void colpiv_qr_factor(const double* Ain, int n, ColPivQR& F) {
+	F.n = n; F.R.assign(Ain, Ain + (size_t)n * n); F.tau.assign(n, 0.0); F.perm.resize(n);
+	std::vector<double>& R = F.R; std::vector<double>& tau = F.tau; std::vector<int>& perm = F.perm;
+	std::vector<double> nrm(n), nrm0(n), w(n), v(n);
 	for (int j = 0; j < n; ++j) { nrm[j] = 0; perm[j] = j; }
 	for (int i = 0; i < n; ++i) {
 		const double* Ri = &R[(size_t)i * n];
@@ -157,12 +173,12 @@ inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x
 		if (std::fabs(beta) > maxpivot) maxpivot = std::fabs(beta);
 		if (tau[k] != 0.0 && k + 1 < n) {
 			const int m = n - (k + 1);
-			double* wk = &w[k + 1];
+			double* __restrict__ wk = &w[k + 1];
 			const double* Rk = &R[(size_t)k * n + k + 1];
 			for (int j = 0; j < m; ++j) wk[j] = Rk[j];
 			for (int i = k + 1; i < n; ++i) {
 				const double vi = R[(size_t)i * n + k];
-				const double* Ri = &R[(size_t)i * n + k + 1];
+				const double* __restrict__ Ri = &R[(size_t)i * n + k + 1];
 				v[i] = vi;
 				for (int j = 0; j < m; ++j) wk[j] += vi * Ri[j];
 			}
@@ -171,7 +187,7 @@ inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x
 			for (int j = 0; j < m; ++j) { wk[j] *= t; Rkw[j] -= wk[j]; }
 			for (int i = k + 1; i < n; ++i) {
 				const double vi = v[i];
-				double* Ri = &R[(size_t)i * n + k + 1];
+				double* __restrict__ Ri = &R[(size_t)i * n + k + 1];
 				for (int j = 0; j < m; ++j) Ri[j] -= wk[j] * vi;
 			}
 		}
@@ -185,6 +201,15 @@ inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x
 			}
 		}
 	}
+	const double thr = maxpivot * (DBL_EPSILON * n);
+	int rank = 0;
+	while (rank < n && std::fabs(R[(size_t)rank * n + rank]) > thr) ++rank;
+	F.rank = rank;
+}
+inline void colpiv_qr_apply(const ColPivQR& F, const double* b, double* x) {
+	const int n = F.n, rank = F.rank;
+	const std::vector<double>& R = F.R; const std::vector<double>& tau = F.tau;
+	std::vector<double> c(b, b + n);
 	// c = Q^T b
 	for (int k = 0; k < n; ++k) {
 		if (tau[k] == 0.0) continue;
@@ -194,16 +219,18 @@ inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x
 		c[k] -= ww;
 		for (int i = k + 1; i < n; ++i) c[i] -= ww * R[(size_t)i * n + k];
 	}
-	const double thr = maxpivot * (DBL_EPSILON * n);
-	int rank = 0;
-	while (rank < n && std::fabs(R[(size_t)rank * n + rank]) > thr) ++rank;
 	std::vector<double> y(n, 0.0);
 	for (int i = rank - 1; i >= 0; --i) {
 		double s = c[i];
 		for (int j = i + 1; j < rank; ++j) s -= R[(size_t)i * n + j] * y[j];
 		y[i] = s / R[(size_t)i * n + i];
 	}
-	for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+	for (int i = 0; i < n; ++i) x[F.perm[i]] = y[i];
+}
+inline void colpiv_qr_solve(const double* Ain, int n, const double* b, double* x) {
+	ColPivQR F;
+	colpiv_qr_factor(Ain, n, F);
+	colpiv_qr_apply(F, b, x);
 }
 
 }	// namespace pano_la

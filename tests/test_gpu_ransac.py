@@ -159,3 +159,44 @@ def test_small_match_lists_span_several_stream_chunks(ctx, oracle, cfg):
         for k in range(len(sizes)):
             _check(oracle, res[k], lists[k], coors[0], coors[1], (600, 400), (600, 400), seeds[k], cfg=c if c is cyl else None)
     mh.free(); f.free()
+
+
+def test_pairwise_table_equals_match_image_bookkeeping(ctx, oracle, cfg):
+    """op_pairwise_table = Stitcher::match_image's bookkeeping (stitch/stitcher.cc:79-93) for the whole job: both directed
+    entries of every accepted pair -- (i, j): the pair's MatchInfo; (j, i): homo.inverse() scaled by 1 / inv[8], matches
+    reversed -- rebuilt here from the per-pair results and the reference's own Homography::inverse (oracle/_ref when it is
+    there, else the host library's restatement)."""
+    import ctypes as C
+    import os
+    from openpano_amd import hip
+    n = 5
+    views = synth.image_set(n, 400, 600, seed=22, overlap=0.45)
+    f = hip.sift_batch(ctx, cfg, views)
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    shapes = [(600, 400)] * n
+    mh = hip.match_pairs_handle(ctx, cfg, f, pairs)
+    lists = mh.lists()
+    res = hip.ransac_pairs(ctx, cfg, f, mh, pairs, shapes, base_seed=42)
+    ij, conf, homo, cnt, pts, nconn = hip.ransac_pairwise_table(ctx, cfg, f, mh, pairs, shapes, base_seed=42)
+    coors = [f.get(i)[1] for i in range(n)]
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openpano_amd", "libpano_host.so"))
+    f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    host.pano_homography_inverse.argtypes = [f64, f64]
+    e = at = 0
+    for p, (i, j) in enumerate(pairs):
+        r = res[p]
+        if not r["ok"]:
+            continue
+        inl = r["inliers"]
+        a = coors[i][lists[p][inl, 0]]; b = coors[j][lists[p][inl, 1]]
+        inv = np.zeros(9); assert host.pano_homography_inverse(np.ascontiguousarray(r["homo"].reshape(9)), inv) == 1
+        inv = inv * (1.0 / inv[8])
+        assert ij[e].tolist() == [i, j] and ij[e + 1].tolist() == [j, i]
+        assert conf[e] == np.float32(r["confidence"]) and conf[e + 1] == conf[e]
+        assert np.array_equal(homo[e], r["homo"].reshape(9)) and np.array_equal(homo[e + 1], inv)
+        assert cnt[e] == len(inl) and cnt[e + 1] == len(inl)
+        assert np.array_equal(pts[at: at + len(inl)], np.concatenate([a, b], 1))
+        assert np.array_equal(pts[at + len(inl): at + 2 * len(inl)], np.concatenate([b, a], 1))
+        at += 2 * len(inl); e += 2
+    assert e == len(ij) == 2 * nconn and at == len(pts) and nconn >= 4
+    mh.free(); f.free()
