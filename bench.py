@@ -451,7 +451,12 @@ def run_blend(hip, ctx, cfg, inputs, H, W, args, log):
                     "stage_ms": {k: round(v, 4) for k, v in prof.items()},
                     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else None, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else None,
-                                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kms}}
+                                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kms,
+                                 # multiband: every level plane (16 B x sum ROI) is written once by the fused blur and read twice (the next
+                                 # blur, the one-pass band kernel): 3 L 16 sum(ROI) moved against SURVEY's 2 L 16 sum(ROI) -- the floor of this
+                                 # formulation is 1.5 x the algorithmic plane bytes, not a re-read to remove
+                                 "moved_over_algorithmic_floor_by_construction": (None if not bcfg.MULTIBAND else
+                                                                                  (alg + 16.0 * res_roi * bcfg.MULTIBAND) / alg)}}
     res["_homos"] = homos
     return res
 

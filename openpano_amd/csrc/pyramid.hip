@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 constexpr int RW_OWN = OP_RW_OWN;     // columns owned by a band
 constexpr int RW_H = RW_OWN + 4;      // row-pass columns: x0 - 2 .. x0 + 241 (one ring column each side is used)
 constexpr int RW_QCAP = 1024;         // scan queue entries per row pair (overflow is handled in place)
+constexpr int RW_RAWCAP = 192;        // raw extrema a workgroup collects in LDS (x | y << 13 | layer << 26); more go straight to the image's list
 
 // wave64 inclusive add-scan on DPP (row_shr within the four rows of 16 lanes, then row_bcast:15 / :31 across rows);
 // call in wave-uniform control flow
@@ -587,6 +588,11 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 	__shared__ float sD[OP_RING_ROWS][6][RW_H];         // |DoG| ring [row & 3][layer][row-pass column]
 	__shared__ unsigned short sQ[RW_QCAP];
 	__shared__ int sQn[2];
+	// Raw extrema found by this workgroup: collected here and appended to the image's list ONCE, at the end.  A global
+	// atomic per found extremum returns a value, and waiting for it (vmcnt(0)) waits for every store the wavefront has in
+	// flight as well -- two of five wavefront-steps found an extremum and paid a write round trip for it.
+	__shared__ unsigned sRaw[RW_RAWCAP];
+	__shared__ int sRawN[2];                                   // [0] entries, [1] this workgroup's first slot in the image's list
 	const int tid = threadIdx.x;
 	// work item; consecutive items (neighbouring bands share cache lines at their seams, neighbouring
 	// segments their halo rows) are handed to one XCD, i.e. one L2
@@ -626,10 +632,38 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 		y = y < 0 ? 0 : (y > od.h - 1 ? od.h - 1 : y);
 		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_grey, xc4, (unsigned)y * (unsigned)od.w * 4u, 0));
 	};
+	// The two grey rows a step fetches are loaded by hand (buffer_load_dword as written, waited for as written).  vmcnt counts
+	// loads AND stores on this target, in issue order, and the number of store instructions a wavefront issues per step is
+	// not a compile-time constant (0, 6 or 12: rows outside the segment store nothing, a band's odd last column takes the
+	// 4-byte form as well), so for a compiler-visible load the wait-count pass must assume NO store lies between the load
+	// and its use: it put `s_waitcnt vmcnt(2)` into the column pass, i.e. waited for every Gaussian-plane store of the
+	// previous step to be acknowledged -- a write round trip per step on the dominant kernel's critical path (the column
+	// pass, 132 packed instructions, took 3900 cycles in the phase trace against 1800 for the row pass with as many).
+	// Here the wavefront knows how many stores it has issued since the loads (a wave-uniform count) and waits for exactly
+	// the loads: `s_waitcnt vmcnt(<stores of this step>)`, at the end of the step.
+	typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+	u32x4v rg;
+	{
+		const unsigned long long ga = (unsigned long long)grey;
+		rg.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
+		rg.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) & 0xFFFFu;     // stride 0
+		rg.z = (unsigned)__builtin_amdgcn_readfirstlane((int)plane_bytes);
+		rg.w = 0x00020000u;
+	}
+	auto grow_issue = [&](int y, float& dst) {
+		y = y < 0 ? 0 : (y > od.h - 1 ? od.h - 1 : y);
+		const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)y * (unsigned)od.w * 4u));
+		asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(xc4), "s"(rg), "s"(so) : "memory");
+	};
 	const __amdgpu_buffer_rsrc_t r_gau = __builtin_amdgcn_make_buffer_rsrc(ws + plane_off_gauss(od, 7, 1), 0, 6u * plane_bytes, 0x00020000);
 	f32x2 win[7];                                                 // grey rows r-6 .. r+7 of the current pair (r, r+1)
 #pragma unroll
 	for (int i = 0; i < 7; ++i) win[i] = f32x2{grow(y0 - 7 + 2 * i), grow(y0 - 6 + 2 * i)};
+	// the window has LANDED before the loop: a load still pending at the loop header would put a wait for it -- and for the
+	// stores issued since -- in front of its use in EVERY iteration
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+	for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(win[i]));
 
 	// row-pass role: row rr of the pair, columns h, h+1 (x = x0 - 2 + h)
 	const int rr = tid >> 7, j = tid & 127, h = 2 * j;
@@ -640,11 +674,25 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 	const bool sc0 = st0 && x >= 1 && x <= od.w - 2, sc1 = st1 && x + 1 <= od.w - 2;   // extrema.cc:212
 	const unsigned allow = (sc0 ? 0x0Fu : 0u) | (sc1 ? 0xF0u : 0u);
 	unsigned pm = 0;                                              // rr == 1: the gate mask of the row produced in the previous pair
-	if (tid < 2) sQn[tid] = 0;
+	if (tid < 2) { sQn[tid] = 0; sRawN[tid] = 0; }
+	const bool packable = od.w < 8192 && od.h < 8192;
+	auto emit_raw = [&](int ex, int ey, int eL) {
+		int e = RW_RAWCAP;
+		if (packable) e = atomicAdd(&sRawN[0], 1);
+		if (e < RW_RAWCAP) sRaw[e] = (unsigned)ex | ((unsigned)ey << 13) | ((unsigned)eL << 26);
+		else {
+			const int sl = atomicAdd(&raw_count[img], 1);
+			if (sl < cap) { int* q = raw + ((long long)img * cap + sl) * 4; q[0] = ex; q[1] = ey; q[2] = o; q[3] = eL; }
+		}
+	};
+	// store instructions this wavefront issues in a step whose row lies inside the segment: six 8-byte stores if any lane
+	// owns a column pair, six 4-byte stores if any lane owns a band's odd last column (each block is skipped when no lane takes it)
+	const int kstores = (__ballot(st1) != 0ULL ? 6 : 0) + (__ballot(st0 && !st1) != 0ULL ? 6 : 0);
 
 	for (int t = 0; t < nsteps; ++t) {
 		const int r = y0 - 1 + 2 * t;
-		const f32x2 nxt = f32x2{grow(r + 8), grow(r + 9)};        // the next pair's two new rows, in flight during this one
+		float nx0, nx1;                                           // the next pair's two new rows, in flight during this one
+		grow_issue(r + 8, nx0); grow_issue(r + 9, nx1);
 		{	// ---- column pass: rows r (window elements 0..12) and r+1 (1..13)
 			// (the chains start from their first product: the reference's `tmp = 0; tmp += ...` (gaussian.hh:60-64) differs
 			// from it only in the sign of a zero sum, which no later stage can observe -- every consumer subtracts or compares)
@@ -783,24 +831,48 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 				const unsigned code = sQ[i];
 				const int hc = code & 255, L = (code >> 8) & 7, qr = code >> 11;
 				const int slot = (2 * t + (qr ? -1 : 0)) & 3;
-				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) {
-					const int s = atomicAdd(&raw_count[img], 1);
-					if (s < cap) { int* q = raw + ((long long)img * cap + s) * 4; q[0] = x0 - 2 + hc; q[1] = r + (qr ? -1 : 0); q[2] = o; q[3] = L; }
-				}
+				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) emit_raw(x0 - 2 + hc, r + (qr ? -1 : 0), L);
 			}
 			for (unsigned m = mine; m; m &= m - 1) {
 				const int b = __ffs(m) - 1, hc = h + (b >> 2), L = (b & 3) + 1;
 				const int slot = (2 * t + (rr ? -1 : 0)) & 3;
-				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) {
-					const int s = atomicAdd(&raw_count[img], 1);
-					if (s < cap) { int* q = raw + ((long long)img * cap + s) * 4; q[0] = x0 - 2 + hc; q[1] = ysc; q[2] = o; q[3] = L; }
-				}
+				if (ring_extremum(sD, slot, L, hc, p.judge_thres)) emit_raw(x0 - 2 + hc, ysc, L);
 			}
 		}
+		// the two rows fetched at the top of the step have landed: everything this wavefront issued since are its stores
+		{
+			const int yrow = r + __builtin_amdgcn_readfirstlane(rr);
+			const int k = (yrow >= y0 && yrow < y0 + rows_own) ? kstores : 0;
+			// (the loaded registers are INPUTS of the wait and the value it produces -- a zero -- is OR-ed into them afterwards:
+			// every use of the rows then depends on the wait, and the compiler has no reason to copy the registers before it,
+			// which a read-write operand invited: it copied them, still in flight, into the operand's own register)
+			unsigned z;
+			if (k == 0) asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0" : "=v"(z) : "v"(nx0), "v"(nx1) : "memory");
+			else if (k == 6) asm volatile("s_waitcnt vmcnt(6)\n\tv_mov_b32 %0, 0" : "=v"(z) : "v"(nx0), "v"(nx1) : "memory");
+			else asm volatile("s_waitcnt vmcnt(12)\n\tv_mov_b32 %0, 0" : "=v"(z) : "v"(nx0), "v"(nx1) : "memory");
+			nx0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx0) | z);
+			nx1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx1) | z);
+		}
+		const f32x2 nxt = f32x2{nx0, nx1};
 		// slide the window by one row pair
 #pragma unroll
 		for (int i = 0; i < 6; ++i) win[i] = win[i + 1];
 		win[6] = nxt;
+	}
+	// append this workgroup's raw extrema to the image's list: one atomic for all of them
+	lds_barrier();
+	int nraw = sRawN[0]; nraw = nraw < RW_RAWCAP ? nraw : RW_RAWCAP;
+	if (nraw > 0) {
+		if (tid == 0) sRawN[1] = atomicAdd(&raw_count[img], nraw);
+		__syncthreads();
+		const int base = sRawN[1];
+		for (int i = tid; i < nraw; i += 256) {
+			const int sl = base + i;
+			if (sl < cap) {
+				const unsigned e = sRaw[i];
+				*(int4*)(raw + ((long long)img * cap + sl) * 4) = make_int4((int)(e & 8191u), (int)((e >> 13) & 8191u), o, (int)(e >> 26));
+			}
+		}
 	}
 }
 

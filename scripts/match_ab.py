@@ -38,8 +38,9 @@ def main():
     jobs = [("config4", [(t.data_ptr(), 867, 1300) for t in d4])]
     if d5:
         jobs.append((f"config5[{a.c5_images}]", [(t.data_ptr(), 3000, 4000, "u8") for t in d5]))
+    product = hip.LIB_PATH                       # openpano_amd/libopenpano_hip.so, or OPENPANO_HIP_LIB (one build per process: profilers)
     for name in ["product"] + list(a.libs):
-        path = os.path.join(ROOT, "openpano_amd", "libopenpano_hip.so") if name == "product" else os.path.abspath(name)
+        path = product if name == "product" else os.path.abspath(name)
         hip._lib = None
         hip.LIB_PATH = path
         ctx = hip.Context(0, stream.cuda_stream)
