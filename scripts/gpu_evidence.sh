@@ -8,8 +8,11 @@
 #   6 micro-benchmarks DESIGN.md quotes: mfma_power, mfma_valu_overlap, lds_atomic_order, the sweep's phase trace (if that variant is built)
 #   7 the SIFT step on 38 / 19 / 10 / 5 of the config-4 images (one rank's share at N = 1 / 2 / 4 / 8)  -> <tag>_sift_shares.txt
 #   8 the whole config-5 job against the oracle, all 8128 pairs (OPENPANO_FULL_C5=1; minutes of host time) -> <tag>_config5_all_pairs.txt
+#     + the record the test writes itself, tied to the library's hash -> config5_all_pairs.json (copy to profiles/config5_all_pairs_latest.json)
+#   9 one-device rehearsal of the 1 / 2 / 4 / 8-rank strong-scaled jobs, config 4 and config 5 (scripts/scale_rehearsal.py)
+#     -> <tag>_scale_rehearsal.json (copy to profiles/scale_rehearsal_latest.json: bench.py --gpus N prints it as `predicted`)
 # Usage: scripts/gpu_evidence.sh <tag> [sections, default "1 2 3 4 5 6 7"]
-tag=${1:-r04}; what=${2:-"1 2 3 4 5 6 7"}
+tag=${1:-r05}; what=${2:-"1 2 3 4 5 6 7"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 has() { [[ " $what " == *" $1 "* ]]; }
@@ -49,6 +52,10 @@ fi
 if has 8; then
   ( time OPENPANO_FULL_C5=1 timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k whole_match_job ) > gpurun_out/${tag}_config5_all_pairs.txt 2>&1
   tail -6 gpurun_out/${tag}_config5_all_pairs.txt
+fi
+if has 9; then
+  ( timeout 600 python scripts/scale_rehearsal.py ${tag} ) > gpurun_out/${tag}_rehearsal.txt 2>&1
+  tail -3 gpurun_out/${tag}_rehearsal.txt
 fi
 python - <<PY
 import json
