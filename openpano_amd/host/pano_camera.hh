@@ -19,6 +19,7 @@
 #include <omp.h>
 #endif
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -187,6 +188,55 @@ inline int ba_threads() {
 }
 inline double ba_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// The bundle adjuster's loops are a few hundred parallel sections of 20-200 microseconds each; an OpenMP fork / join per
+// section costs as much as the section on a big host (threads that went to sleep between two sections take tens of
+// microseconds to come back: 747 LM iterations x 3 sections were 120 of the 127 ms of an estimate).  One parallel region
+// therefore spans a whole optimize() call: thread 0 runs the serial Levenberg-Marquardt logic, the others spin on an epoch
+// counter and join every section it publishes (items handed out by an atomic counter).  Sections only ever write disjoint
+// outputs and every output's own arithmetic is sequential, so which thread runs an item changes no bit.
+class BaTeam {
+	public:
+		explicit BaTeam(int threads): nthreads(threads) {}
+		void set_threads(int t) { nthreads = t; }
+		// thread 0: run items 0..n-1 of f with the team; returns when all are done
+		void run(int n_items, const std::function<void(int)>& f) {
+			if (nthreads <= 1 || n_items < 2) { for (int i = 0; i < n_items; ++i) f(i); return; }
+			fn = &f; n = n_items;
+			next.store(0, std::memory_order_relaxed); done.store(0, std::memory_order_relaxed);
+			epoch.fetch_add(1, std::memory_order_release);
+			work();
+			while (done.load(std::memory_order_acquire) != nthreads - 1) relax();
+		}
+		// threads 1..: until thread 0 calls finish()
+		void worker_loop() {
+			unsigned seen = 0;
+			for (;;) {
+				unsigned e;
+				while ((e = epoch.load(std::memory_order_acquire)) == seen) {
+					if (quit.load(std::memory_order_acquire)) return;
+					relax();
+				}
+				seen = e;
+				work();
+				done.fetch_add(1, std::memory_order_release);
+			}
+		}
+		void finish() { quit.store(true, std::memory_order_release); }
+	private:
+		int nthreads;
+		std::atomic<unsigned> epoch{0};
+		std::atomic<int> next{0}, done{0};
+		std::atomic<bool> quit{false};
+		const std::function<void(int)>* fn = nullptr;
+		int n = 0;
+		void work() { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; (*fn)(i); } }
+		static void relax() {
+#if defined(__x86_64__)
+			__builtin_ia32_pause();
+#endif
+		}
+};
+
 class IncrementalBundleAdjuster {
 	public:
 		struct ErrorStats {
@@ -227,6 +277,32 @@ class IncrementalBundleAdjuster {
 		void optimize() {
 			if (idx_added.empty()) pano_error_exit("Calling optimize() without adding any matches!");
 			ba_prof().n_opt++;
+#ifdef _OPENMP
+			// one parallel region for the whole call (BaTeam above): thread 0 optimizes, the others serve its sections
+			BaTeam t(ba_threads());
+#pragma omp parallel num_threads(ba_threads()) proc_bind(close)
+			{
+				if (omp_get_thread_num() == 0) {
+					t.set_threads(omp_get_num_threads());
+					team = &t;
+					optimize_serial();
+					team = nullptr;
+					t.finish();
+				} else t.worker_loop();
+			}
+#else
+			optimize_serial();
+#endif
+		}
+		double last_error = 0; int last_iterations = 0;
+
+	protected:
+		BaTeam* team = nullptr;                 // set while optimize() runs: the sections below are shared out to it
+		void team_for(int n, const std::function<void(int)>& f) {
+			if (team) team->run(n, f);
+			else for (int i = 0; i < n; ++i) f(i);
+		}
+		void optimize_serial() {
 			update_index_map();
 			const int nr_img = (int)idx_added.size();
 			JtJ.assign((size_t)(NR_PARAM_PER_CAMERA * nr_img) * (NR_PARAM_PER_CAMERA * nr_img), 0.0);
@@ -261,9 +337,6 @@ class IncrementalBundleAdjuster {
 			int now = 0;
 			for (auto& i : idx_added) result_cameras[i] = results[now++];
 		}
-		double last_error = 0; int last_iterations = 0;
-
-	protected:
 		static constexpr int NR_PARAM_PER_CAMERA = 6, NR_TERM_PER_MATCH = 2, LM_MAX_ITER = 100;
 		std::vector<Camera>& result_cameras;
 		struct MatchPair {
@@ -341,8 +414,7 @@ class IncrementalBundleAdjuster {
 			const double t0 = ba_now();
 			auto cameras = state.get_cameras();
 			const int npairs = (int)match_pairs.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads()) proc_bind(close)            // independent residuals: each pair writes its own slice
-			for (int q = 0; q < npairs; ++q) {
+			team_for(npairs, [&](int q) {                        // independent residuals: each pair writes its own slice
 				const MatchPair& pair = match_pairs[q];
 				int idx = match_cnt_prefix_sum[q] * 2;
 				const int from = index_map[pair.from], to = index_map[pair.to];
@@ -355,7 +427,7 @@ class IncrementalBundleAdjuster {
 					ret.residuals[idx + 1] = from2.y - transformed.y;
 					idx += 2;
 				}
-			}
+			});
 			ret.update_stats(inlier_threshold);
 			ba_prof().t_err += ba_now() - t0;
 			return ret;
@@ -420,9 +492,7 @@ class IncrementalBundleAdjuster {
 			const int nr_img = (int)idx_added.size();
 			const int np = nr_img * NR_PARAM_PER_CAMERA;
 			if (!fresh) {              // same state as the previous call: the derivative rows and JtJ stand; J^T r with the new residuals
-				const int ndiag0 = nr_img;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads()) proc_bind(close)
-				for (int c = 0; c < ndiag0; ++c) {
+				team_for(nr_img, [&](int c) {
 					double g[6] = {0, 0, 0, 0, 0, 0};
 					for (int q : cam_pairs[c]) {
 						const MatchPair& pair = match_pairs[q];
@@ -437,7 +507,7 @@ class IncrementalBundleAdjuster {
 						}
 					}
 					for (int a = 0; a < 6; ++a) Jtr[c * NR_PARAM_PER_CAMERA + a] = g[a];
-				}
+				});
 				return;
 			}
 			std::fill(JtJ.begin(), JtJ.end(), 0.0);
@@ -452,8 +522,7 @@ class IncrementalBundleAdjuster {
 			const int npairs = (int)match_pairs.size();
 
 			// ---- phase 1: derivative rows of every match
-#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads()) proc_bind(close)
-			for (int pair_idx = 0; pair_idx < npairs; ++pair_idx) {
+			team_for(npairs, [&](int pair_idx) {
 				const MatchPair& pair = match_pairs[pair_idx];
 				const int from = index_map[pair.from], to = index_map[pair.to];
 				const auto& c_from = cameras[from]; const auto& c_to = cameras[to];
@@ -505,12 +574,11 @@ class IncrementalBundleAdjuster {
 					drdv(11, Dto[2].trans(dot_u2));
 					row += 24;
 				}
-			}
+			});
 
 			// ---- phase 2: one task per 6 x 6 block (diagonal blocks also own their camera's J^T r slice)
 			const int ndiag = nr_img, noff = (int)block_pairs.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(ba_threads()) proc_bind(close)
-			for (int task = 0; task < ndiag + noff; ++task) {
+			team_for(ndiag + noff, [&](int task) {
 				if (task < ndiag) {
 					const int c = task;
 					double L[6][6] = {{0}}, g[6] = {0, 0, 0, 0, 0, 0};
@@ -564,7 +632,7 @@ class IncrementalBundleAdjuster {
 						JtJ[(size_t)(bj + b) * np + bi + a] = L[a][b];
 					}
 				}
-			}
+			});
 		}
 };
 
