@@ -198,6 +198,7 @@ class BaTeam {
 	public:
 		explicit BaTeam(int threads): nthreads(threads) {}
 		void set_threads(int t) { nthreads = t; }
+		int threads() const { return nthreads; }
 		// thread 0: run items 0..n-1 of f with the team; returns when all are done
 		void run(int n_items, const std::function<void(int)>& f) {
 			if (nthreads <= 1 || n_items < 2) { for (int i = 0; i < n_items; ++i) f(i); return; }
@@ -414,7 +415,10 @@ class IncrementalBundleAdjuster {
 			const double t0 = ba_now();
 			auto cameras = state.get_cameras();
 			const int npairs = (int)match_pairs.size();
-			team_for(npairs, [&](int q) {                        // independent residuals: each pair writes its own slice
+			// (serial: 16 us of arithmetic per call at 49 k matches, and thread 0 reads every residual right after for the
+			// sequential error statistic -- sharing the loop out moved the residuals through sixteen caches: 12 -> 18-27 ms per estimate)
+			auto serial_for = [](int n, const std::function<void(int)>& f) { for (int i = 0; i < n; ++i) f(i); };
+			serial_for(npairs, [&](int q) {                      // independent residuals: each pair writes its own slice
 				const MatchPair& pair = match_pairs[q];
 				int idx = match_cnt_prefix_sum[q] * 2;
 				const int from = index_map[pair.from], to = index_map[pair.to];
@@ -492,21 +496,25 @@ class IncrementalBundleAdjuster {
 			const int nr_img = (int)idx_added.size();
 			const int np = nr_img * NR_PARAM_PER_CAMERA;
 			if (!fresh) {              // same state as the previous call: the derivative rows and JtJ stand; J^T r with the new residuals
-				team_for(nr_img, [&](int c) {
+				// (a camera's slice is three tasks of two parameters each: a well-connected camera walks thousands of matches, and
+				// one task per camera made the busiest camera the section's critical path; every entry's own chain is unchanged)
+				const int split = 1, rows = 6 / split;      // (a three-way split of a camera's parameters shortens the busiest camera's pass but reads every derivative row three times: 57 -> 67 ms per estimate on the 256-CPU host)
+				team_for(split * nr_img, [&](int task) {
+					const int c = task / split, a0 = rows * (task % split);
 					double g[6] = {0, 0, 0, 0, 0, 0};
 					for (int q : cam_pairs[c]) {
 						const MatchPair& pair = match_pairs[q];
 						const int nm = (int)pair.m.match.size();
 						const double* row = deriv.data() + (size_t)match_cnt_prefix_sum[q] * 24;
 						const double* res = residual.data() + (size_t)match_cnt_prefix_sum[q] * 2;
-						const int o = index_map[pair.from] == c ? 0 : 6;
+						const int o = (index_map[pair.from] == c ? 0 : 6) + a0;
 						for (int k = 0; k < nm; ++k, row += 24, res += 2) {
 							const double* dx = row + o; const double* dy = row + 12 + o;
 							const double rx = res[0], ry = res[1];
-							for (int a = 0; a < 6; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
+							for (int a = 0; a < rows; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
 						}
 					}
-					for (int a = 0; a < 6; ++a) Jtr[c * NR_PARAM_PER_CAMERA + a] = g[a];
+					for (int a = 0; a < rows; ++a) Jtr[c * NR_PARAM_PER_CAMERA + a0 + a] = g[a];
 				});
 				return;
 			}
@@ -577,10 +585,13 @@ class IncrementalBundleAdjuster {
 			});
 
 			// ---- phase 2: one task per 6 x 6 block (diagonal blocks also own their camera's J^T r slice)
-			const int ndiag = nr_img, noff = (int)block_pairs.size();
+			// (a diagonal block is three tasks of two rows each -- rows a0, a0 + 1 of the block's upper triangle and the same two
+			// entries of J^T r: one task per camera made the best-connected camera the section's critical path)
+			const int split = 1, rows = 6 / split;         // (see above: splitting a diagonal block over tasks did not pay)
+			const int ndiag = split * nr_img, noff = (int)block_pairs.size();
 			team_for(ndiag + noff, [&](int task) {
 				if (task < ndiag) {
-					const int c = task;
+					const int c = task / split, a0 = rows * (task % split), a1 = a0 + rows;
 					double L[6][6] = {{0}}, g[6] = {0, 0, 0, 0, 0, 0};
 					for (int q : cam_pairs[c]) {
 						const MatchPair& pair = match_pairs[q];
@@ -595,13 +606,13 @@ class IncrementalBundleAdjuster {
 						for (int k = 0; k < nm; ++k, row += 24, res += 2) {
 							const double* dx = row + o; const double* dy = row + 12 + o;
 							const double rx = res[0], ry = res[1];
-							for (int a = 0; a < 6; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
-							for (int a = 0; a < 6; ++a)
+							for (int a = a0; a < a1; ++a) { g[a] += dx[a] * rx; g[a] += dy[a] * ry; }
+							for (int a = a0; a < a1; ++a)
 								for (int b = a; b < 6; ++b) L[a][b] += dx[a] * dx[b] + dy[a] * dy[b];
 						}
 					}
 					const int base = c * NR_PARAM_PER_CAMERA;
-					for (int a = 0; a < 6; ++a) {
+					for (int a = a0; a < a1; ++a) {
 						Jtr[base + a] = g[a];
 						for (int b = a; b < 6; ++b) { JtJ[(size_t)(base + a) * np + base + b] = L[a][b]; JtJ[(size_t)(base + b) * np + base + a] = L[a][b]; }
 					}
