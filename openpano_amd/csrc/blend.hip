@@ -286,12 +286,24 @@ __global__ void __launch_bounds__(256) k_mb_blur(const BlendImg* __restrict__ im
 // sum over images has a single term, (cur - next) * 1 / 1: the winner's thread holds cur (its column window) and next
 // (just computed) and stores the band into the untouched target -- the level-0 pass of k_mb_accumulate (a read of
 // every image's ROI plane) disappears.
+// Waits (round 5).  vmcnt counts loads AND stores, in issue order, and __syncthreads() carries a workgroup fence that waits
+// for every store in flight: the first form of this kernel -- store row r, load row r + CT + 1, __syncthreads() -- waited
+// for the acknowledgement of the row it had just written, once per row.  Now (i) the barrier is LDS-only (the rows written
+// are never read back here), (ii) the source row of the NEXT iteration is requested at the top of an iteration, i.e. BEFORE
+// this iteration's stores, so that its wait (one iteration later) has only those stores behind it, and (iii) every
+// wavefront issues the same number of store instructions per row -- lanes that must not write get an offset beyond the
+// buffer descriptor's range, which the hardware drops -- so that number is a compile-time constant and the compiler's own
+// wait for the load is `vmcnt(<stores>)`: no store acknowledgement is ever waited for.  The window holds one row more
+// (2 CT + 2 slots: the row in flight must not land on a row still in use), hence segments of k x (2 CT + 2) rows.
+__device__ __forceinline__ void blur_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 template <int CT, bool FIRST>
 __global__ void __launch_bounds__(256) k_mb_blur_fused(const BlendImg* __restrict__ imgs, BlurTaps taps,
 		const float4* __restrict__ src, float4* __restrict__ dst, float* __restrict__ target, unsigned char* __restrict__ tmask, int H, int W) {
 	constexpr int NT = 2 * CT + 1;          // taps
+	constexpr int NS = NT + 1;              // window slots
 	constexpr int TWO = 256 - 2 * CT;       // output columns of a band
-	constexpr int SEG = (CT <= 6 ? 8 : 6) * NT;   // rows of a segment (a whole number of window rotations; its 2 CT halo rows are re-read: 12 % / 16 %)
+	constexpr int SEG = (CT <= 6 ? 8 : 6) * NS;   // rows of a segment (a whole number of window rotations; its 2 CT halo rows are re-read)
 	__shared__ float4 s_mid[2][256];
 	const BlendImg& im = imgs[blockIdx.y];
 	const int rw = im.rw, rh = im.rh;
@@ -309,45 +321,57 @@ __global__ void __launch_bounds__(256) k_mb_blur_fused(const BlendImg* __restric
 #pragma unroll
 	for (int k = 0; k < NT; ++k) kk[k] = taps.k[k];
 	auto row_at = [&](int r) { const int rc = r < 0 ? 0 : (r > rh - 1 ? rh - 1 : r); return base[(long long)rc * rw + xc]; };
-	float4 v[NT];                           // v[(r + CT) % NT ... ]: rows r - CT .. r + CT of this column, rotating
+	float4 v[NS];                           // slot of row q is (q - (r0 - CT)) % NS
 #pragma unroll
-	for (int k = 0; k < NT - 1; ++k) v[k] = row_at(r0 - CT + k);
-	// window slot of row (r0 - CT + q) is q % NT; the row that enters at step u (0-based within a rotation) is
-	// r + CT = r0 + CT + u -> slot (2 CT + u) % NT = (u + NT - 1) % NT
-	for (int rb = r0; rb < r1; rb += NT) {
+	for (int k = 0; k < NT; ++k) v[k] = row_at(r0 - CT + k);   // rows r0 - CT .. r0 + CT: the first row's whole window
+	const unsigned row_bytes = (unsigned)rw * 16u;
+	const unsigned xoff = writer ? (unsigned)x * 16u : 0x80000000u;       // beyond any row: dropped
+	for (int rb = r0; rb < r1; rb += NS) {
 #pragma unroll
-		for (int u = 0; u < NT; ++u) {
+		for (int u = 0; u < NS; ++u) {
 			const int r = rb + u;
-			v[(u + NT - 1) % NT] = row_at(r + CT);
+			// the NEXT row's last source row, requested before this row's stores; its slot held row r - CT - 1, dead since the previous row
+			v[(u + NT) % NS] = row_at(r + CT + 1);
 			float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-			for (int k = 0; k < NT; ++k) {                   // tap k multiplies row r - CT + k = slot (u + k) % NT
-				const float4 s = v[(u + k) % NT]; const float kv = kk[k];
+			for (int k = 0; k < NT; ++k) {                   // tap k multiplies row r - CT + k = slot (u + k) % NS
+				const float4 s = v[(u + k) % NS]; const float kv = kk[k];
 				c.w += s.w * kv; c.x += s.x * kv; c.y += s.y * kv; c.z += s.z * kv;
 			}
 			s_mid[(r - r0) & 1][t] = c;                       // double buffered: the readers of row r - 1 may still be at work
-			__syncthreads();
-			if (writer && r < r1) {
+			blur_lds_barrier();
+			float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (writer) {
 				const float4* m = &s_mid[(r - r0) & 1][t - CT];
-				float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 				for (int k = 0; k < NT; ++k) {
 					const float4 s = m[k]; const float kv = kk[k];
 					o.w += s.w * kv; o.x += s.x * kv; o.y += s.y * kv; o.z += s.z * kv;
 				}
-				out[(long long)r * rw + x] = o;
-				if (FIRST) {
-					const float4 cc = v[(u + CT) % NT];              // level-0 pixel (r, x): the centre tap's row of this thread's own column
-					const int ti = im.y0 + r, tj = im.x0 + x;
-					if (cc.w > 0 && ti < H && tj < W) {              // the winner (weight 1); a masked pixel has weight 0
-						float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
-						s0 += (cc.x - o.x) * cc.w; s1 += (cc.y - o.y) * cc.w; s2 += (cc.z - o.z) * cc.w; wsum += cc.w;
-						s0 /= wsum; s1 /= wsum; s2 /= wsum;
-						const long long pe = (long long)ti * W + tj;
-						target[pe * 3] = s0; target[pe * 3 + 1] = s1; target[pe * 3 + 2] = s2;
-						tmask[pe] = 1;
-					}
-				}
+			}
+			// one 16-byte store instruction per wavefront and row, whatever its lanes do (rows past the segment: dropped as well)
+			const bool live = r < r1;
+			{
+				const int rc = live ? r : 0;
+				const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (long long)rc * rw, 0, live ? row_bytes : 0u, 0x00020000);
+				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, o), rs, xoff, 0, 0);
+			}
+			if (FIRST) {
+				const float4 cc = v[(u + CT) % NS];              // level-0 pixel (r, x): the centre tap's row of this thread's own column
+				const int ti = im.y0 + r, tj = im.x0 + x;
+				const bool win = writer && live && cc.w > 0 && ti < H && tj < W;     // the winner (weight 1); a masked pixel has weight 0
+				float s0 = 0.f, s1 = 0.f, s2 = 0.f, wsum = 0.f;
+				s0 += (cc.x - o.x) * cc.w; s1 += (cc.y - o.y) * cc.w; s2 += (cc.z - o.z) * cc.w; wsum += cc.w;
+				s0 /= wsum; s1 /= wsum; s2 /= wsum;
+				const bool rowok = live && ti < H;
+				const int tic = rowok ? ti : 0;
+				const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(target + (long long)tic * W * 3, 0, rowok ? (unsigned)W * 12u : 0u, 0x00020000);
+				const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(tmask + (long long)tic * W, 0, rowok ? (unsigned)W : 0u, 0x00020000);
+				const unsigned to = win ? (unsigned)tj * 12u : 0x80000000u, mo = win ? (unsigned)tj : 0x80000000u;
+				__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s0), rt, to, 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s1), rt, to, 4, 0);
+				__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s2), rt, to, 8, 0);
+				__builtin_amdgcn_raw_buffer_store_b8((unsigned char)1, rm, mo, 0, 0);
 			}
 		}
 	}
@@ -874,7 +898,7 @@ int op_blend(op_ctx* ctx, const op_config* cfg, const op_blend_geom* g, const op
 					pool_free(cv->data); delete cv; OP_FAIL(OP_ERR_UNSUPPORTED, "op_blend: Gaussian kernel wider than 31 taps");
 				}
 				if (taps.center == 6 || taps.center == 9) {       // shipped GAUSS_WINDOW_FACTOR: both passes in one kernel
-					const int C = taps.center, two = 256 - 2 * C, segr = (C <= 6 ? 8 : 6) * (2 * C + 1);
+					const int C = taps.center, two = 256 - 2 * C, segr = (C <= 6 ? 8 : 6) * (2 * C + 2);      // k_mb_blur_fused: SEG
 					unsigned items = 1;
 					for (int k = 0; k < n; ++k)
 						items = std::max(items, (unsigned)(((h_imgs[k].rw + two - 1) / two) * ((h_imgs[k].rh + segr - 1) / segr)));

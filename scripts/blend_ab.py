@@ -35,8 +35,13 @@ def main():
         hip.LIB_PATH = path
         ctx = hip.Context(0, stream.cuda_stream)
         res = bench.run_blend(hip, ctx, PanoConfig(), inputs, H, W, a, lambda m: None)
+        homos = res.pop("_homos")
+        crcs = []
+        for mb in (0, 5):
+            cv = hip.blend(ctx, PanoConfig(MULTIBAND=mb), inputs, homos, 2, len(inputs) // 2)
+            crcs.append("%08x" % zlib.crc32(cv.numpy().tobytes())); cv.free()
         short = os.path.basename(path).replace("libopenpano_hip_", "").replace(".so", "")
-        print(f"{short:20s} " + "  ".join(f"{k}: {v['ms_per_blend']:.4f} ms {v['stage_ms']}" for k, v in res.items()), flush=True)
+        print(f"{short:20s} crc {crcs}  " + "  ".join(f"{k}: {v['ms_per_blend']:.4f} ms {v['stage_ms']}" for k, v in res.items()), flush=True)
         ctx.close()
 
 
