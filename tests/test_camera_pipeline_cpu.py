@@ -55,3 +55,27 @@ def test_rendered_views_to_cameras(oracle, ref, n, rows, step):
         Rtrue = Rs[a] @ Rs[b].T
         ang = np.rad2deg(np.arccos(np.clip((np.trace(Rrel @ Rtrue.T) - 1) / 2, -1, 1)))
         assert ang < 1.5, (a, b, ang)
+
+
+def test_bundle_adjuster_team_size_changes_no_bit(tmp_path):
+    """The bundle adjuster's sections are shared out to a spinning team inside ONE parallel region per optimize() call
+    (pano_camera.hh: BaTeam); which thread runs an item must change no bit.  The team size is read once per process
+    (PANO_BA_THREADS), so every size gets a process of its own; the table is the probe's (38 cameras, rendered)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from camera_util import host_impl, rotating_camera_scene\n"
+        "shapes, table, _ = rotating_camera_scene(5, n=12, rows=2, w=640, h=480, focal=700., step_deg=16.0, npts=90)\n"
+        "np.save(sys.argv[1], host_impl().estimate(shapes, table))\n" % here)
+    outs = []
+    for t in (1, 2, 5):
+        f = str(tmp_path / f"cams_{t}.npy")
+        env = dict(os.environ, PANO_BA_THREADS=str(t))
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert outs[0].shape == (12, 13) and np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
