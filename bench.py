@@ -673,6 +673,18 @@ def main():
     ransac_inputs, blend_homos = None, None
     args.H, args.W = H, W
     args.pmc, args.pmc_src = pmc, pmc_src          # replayed counters of THIS build (or {}): the matcher's MFMA utilisation
+    args.c5mfma = None
+    try:
+        c5p = os.path.join(ROOT, "profiles", "config5_mfma_latest.json")
+        if os.path.exists(c5p):
+            import hashlib
+            c5m = json.load(open(c5p))
+            if c5m.get("_meta", {}).get("lib_sha256_16") == hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16]:
+                args.c5mfma = c5m
+            else:
+                log("profiles/config5_mfma_latest.json belongs to another build of the library: config-5 matrix-pipe counters dropped")
+    except Exception as e:
+        log(f"config5_mfma_latest.json not usable: {e}")
     if hasattr(hip, "match_pairs") and not args.no_match:
         from bench_match import run_job_loops
         out["match"] = run_job_loops(hip, ctx, cfg, feats, n_total, [(W, H)] * n_total, args, dist, dev, rank, world, barrier, log,
@@ -820,6 +832,9 @@ def main():
             "blend_linear_cpu_mpix_per_s": (((out.get("blend") or {}).get("linear") or {}).get("cpu_baseline") or {}).get("value"),
             "roofline_frac": (roofline or {}).get("frac"), "roofline_kernel": (roofline or {}).get("kernel"),
             "config5_match_mfma_frac": (c5.get("match_roofline") or {}).get("frac"), "config5_phase_ms": c5.get("phase_ms"),
+            "config5_mfma_busy": (c5.get("match_roofline") or {}).get("mfma_busy_config5_forward"),
+            "config5_shader_clock_ghz": (c5.get("match_roofline") or {}).get("shader_clock_ghz_under_the_sweep"),
+            "config5_frac_of_peak_at_that_clock": (c5.get("match_roofline") or {}).get("frac_of_peak_at_that_clock"),
             "parity_checked": out.get("parity_checked"),
             "config5_parity_pairs": (c5.get("parity") or {}).get("pairs"),
             "note": "value = inputs resident in HBM (bench contract); protocol_* = SURVEY 8(d) timing protocol incl. H2D and D2H; north_star's >= 30x is met by value and by protocol_u8, protocol_f32 is PCIe-bound",

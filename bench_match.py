@@ -265,6 +265,19 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
            "sift_stage_ms": {x: round(v, 4) for x, v in prof.items() if not x.startswith("matcher")},
            "match_roofline": _mfma_roofline(prof, flops, getattr(args, "pmc", None), getattr(args, "pmc_src", None)),
            "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
+    if kind == "config5" and res["match_roofline"] is not None:
+        # The matrix-pipe counters of THESE launches (the per-kernel averages replayed above are dominated by config 4's short
+        # workgroups): per-dispatch MfmaUtil and the shader clock the chip holds under the sweep, from a counter pass over this
+        # build (scripts/pmc_config5_mfma.py -> profiles/config5_mfma_latest.json, hash-checked like pmc_latest.json)
+        c5 = getattr(args, "c5mfma", None)
+        if c5:
+            f5 = c5["config5_forward"]
+            rl = res["match_roofline"]
+            rl["mfma_busy_config5_forward"] = f5["mfma_busy"]
+            rl["shader_clock_ghz_under_the_sweep"] = f5["shader_clock_ghz"]
+            rl["peak_at_that_clock_tflops"] = f5["peak_tflops_at_measured_clock"]
+            rl["frac_of_peak_at_that_clock"] = rl["achieved"] / f5["peak_tflops_at_measured_clock"]
+            rl["mfma_busy_config5_source"] = f"replayed from profiles/config5_mfma_latest.json (lib_sha256_16 {c5['_meta']['lib_sha256_16']}; not collected in this run)"
     if parity and world == 1:
         t0 = time.perf_counter()
         # config 5: as many pairs as ONE rank of an 8-GPU job owns (8128 / 8 = 1016), half of them overlapping views

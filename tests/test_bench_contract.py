@@ -127,3 +127,22 @@ def test_full_job_record_belongs_to_the_built_library():
     got = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     if rec["lib_sha256_16"] != got:
         pytest.skip(f"STALE: the full config-5 parity job ran on library {rec['lib_sha256_16']}, the built library is {got}")
+
+
+def test_config5_matrix_pipe_counters_belong_to_the_built_library():
+    """profiles/config5_mfma_latest.json (per-dispatch matrix-pipe counters of the config-5 sweeps) is replayed by bench.py only for
+    the library it was collected on; a mismatch is reported as a skip like the other counter records."""
+    import hashlib
+    import json
+    import pytest
+    lib = os.path.join(ROOT, "openpano_amd", "libopenpano_hip.so")
+    rec = os.path.join(ROOT, "profiles", "config5_mfma_latest.json")
+    if not (os.path.exists(lib) and os.path.exists(rec)):
+        pytest.skip("library or record not present")
+    d = json.load(open(rec))
+    f5 = d["config5_forward"]
+    assert 0 < f5["mfma_busy"] <= 1 and 1.0 < f5["shader_clock_ghz"] < 2.6 and f5["workgroups"] > 100000
+    assert abs(f5["peak_tflops_at_measured_clock"] - 1024 * 1024 * f5["shader_clock_ghz"] * 1e-3) < 1.0
+    got = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    if d["_meta"]["lib_sha256_16"] != got:
+        pytest.skip(f"STALE: the config-5 matrix-pipe counters were collected on library {d['_meta']['lib_sha256_16']}, the built library is {got}")
