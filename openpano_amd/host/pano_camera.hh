@@ -29,6 +29,7 @@
 #include <queue>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pano_types.hh"
@@ -206,16 +207,16 @@ class BaTeam {
 			next.store(0, std::memory_order_relaxed); done.store(0, std::memory_order_relaxed);
 			epoch.fetch_add(1, std::memory_order_release);
 			work();
-			while (done.load(std::memory_order_acquire) != nthreads - 1) relax();
+			for (unsigned spins = 0; done.load(std::memory_order_acquire) != nthreads - 1; ++spins) relax(spins);
 		}
 		// threads 1..: until thread 0 calls finish()
 		void worker_loop() {
 			unsigned seen = 0;
 			for (;;) {
 				unsigned e;
-				while ((e = epoch.load(std::memory_order_acquire)) == seen) {
+				for (unsigned spins = 0; (e = epoch.load(std::memory_order_acquire)) == seen; ++spins) {
 					if (quit.load(std::memory_order_acquire)) return;
-					relax();
+					relax(spins);
 				}
 				seen = e;
 				work();
@@ -231,10 +232,12 @@ class BaTeam {
 		const std::function<void(int)>* fn = nullptr;
 		int n = 0;
 		void work() { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; (*fn)(i); } }
-		static void relax() {
+		// a pause per poll; on a host with fewer free cores than team members the waiters must not starve the thread they wait for
+		static void relax(unsigned spins) {
 #if defined(__x86_64__)
 			__builtin_ia32_pause();
 #endif
+			if ((spins & 0xFFFu) == 0xFFFu) std::this_thread::yield();
 		}
 };
 
