@@ -289,8 +289,8 @@ int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, co
  * BlenderBase::add_image takes the coordinate map as a std::function (stitch/blender.hh:52-56),
  * which a device cannot call, so the seam sits one level up and the map travels as PODs:
  * projection method, proj_range.min, resolution and homo_inv per image.
- * Pixels are the reference's to within 1e-4 (identical whenever the device's fp64 sin/cos/tan
- * round like glibc's; colour arithmetic is the reference's fp32 sequence); Color::NO = -1 marks
+ * Pixels are the reference's, bit for bit, for every projection (the map's sin / cos / tan are tabulated per canvas
+ * column / row by the host libm, colour arithmetic is the reference's fp32 sequence); Color::NO = -1 marks
  * "no pixel" on input and output (lib/color.cc:11-15).
  * ===================================================================================== */
 typedef struct op_blend_image {

@@ -2,7 +2,7 @@
 
 * config 4 as bench.py times it: all 38 synthetic 1300x867 views -> op_sift_batch -> all 703 pairs
   -> op_ransac_pairs -> op_blend; every descriptor, coordinate, match set, RANSAC winner / inlier
-  set / homography equal to the oracle's (bit-exact), the panorama within 1e-4.
+  set / homography and the blended panorama equal to the oracle's (bit-exact).
   (stitcher.cc:96-113 pair loop, stitcherbase.cc:9-27 image loop.)
 * the same on natural texture (tests/natural.py: 38 crops of the reference's published uav panorama).
 * a config-5-shaped job: 32 of the 128 4000x3000 uint8 images, all 496 pairs, K ~ 3-5 k per image:
