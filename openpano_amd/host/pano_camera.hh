@@ -331,7 +331,7 @@ class IncrementalBundleAdjuster {
 				new_state.params = state.get_params();
 				for (size_t i = 0; i < new_state.params.size(); ++i)
 					if (i < idt * 6 + 3 || i >= idt * 6 + 6) new_state.params[i] -= update[i];     // R of the identity image stays
-				err_stat = calcError(new_state);
+				calcError(new_state, err_stat);        // (in place: the residuals of the previous trial were consumed by get_param_update above)
 				if (err_stat.avg >= best_err - 1e-3) { nr_non_decrease++; fresh = false; }
 				else { nr_non_decrease = 0; best_err = err_stat.avg; state = std::move(new_state); fresh = true; }
 				if (nr_non_decrease > 5) break;
@@ -415,6 +415,13 @@ class IncrementalBundleAdjuster {
 
 		ErrorStats calcError(const ParamState& state) {            // :179-206
 			ErrorStats ret(nr_pointwise_match * NR_TERM_PER_MATCH);
+			calcError(state, ret);
+			return ret;
+		}
+		// the same into a caller-owned object: the LM loop computes ~250 of these per estimate, and a fresh 0.8-MB vector each time
+		// is an mmap, its page faults and a munmap (every residual is assigned below, nothing relies on the zero fill)
+		void calcError(const ParamState& state, ErrorStats& ret) {
+			ret.residuals.resize((size_t)nr_pointwise_match * NR_TERM_PER_MATCH);
 			const double t0 = ba_now();
 			auto cameras = state.get_cameras();
 			const int npairs = (int)match_pairs.size();
@@ -437,7 +444,6 @@ class IncrementalBundleAdjuster {
 			});
 			ret.update_stats(inlier_threshold);
 			ba_prof().t_err += ba_now() - t0;
-			return ret;
 		}
 
 		// (JtJ + damping) x = J^T r  (:231-251)
@@ -521,11 +527,13 @@ class IncrementalBundleAdjuster {
 				});
 				return;
 			}
-			std::fill(JtJ.begin(), JtJ.end(), 0.0);
-			std::fill(Jtr.begin(), Jtr.end(), 0.0);
+			// (JtJ was zeroed when optimize() sized it: every block of a connected camera pair, every diagonal block and every entry of
+			// J^T r is ASSIGNED below, the blocks of unconnected pairs are never touched -- 0.4 MB of fill per call were for nothing)
 			const auto& cameras = state.get_cameras();
 			std::vector<std::array<Homography, 3>> all_dRdvi(cameras.size());
-			for (size_t i = 0; i < cameras.size(); ++i) all_dRdvi[i] = dRdvi(cameras[i].R);
+			// (one 3 x 3 Jacobi SVD per camera inside rotation_to_angle: 0.2-0.3 ms per fresh Jacobian when one thread does them all,
+			// more than the sixteenth of either phase below that a team member gets)
+			team_for((int)cameras.size(), [&](int i) { all_dRdvi[i] = dRdvi(cameras[i].R); });
 			const double kf[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0}, kx[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0}, ky[9] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
 			const Homography dKdfocal(kf), dKdppx(kx), dKdppy(ky);
 			update_topology(nr_img);
