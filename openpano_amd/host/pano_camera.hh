@@ -180,7 +180,9 @@ inline int ba_threads() {
 		int t = 1;
 #ifdef _OPENMP
 		t = omp_get_max_threads();
-		if (t > 16) t = 16;      // measured on a 256-CPU host: 16 threads 99 ms, 32 threads 145 ms, 1 thread 240 ms per estimate
+		// measured on a 256-CPU host (2 x EPYC 9575F), natural-sized table, per estimate: 1 thread 101 ms, 8 threads 51 ms, 16 threads
+		// 52-56 ms, 24 threads 55-100 ms: eight cores share one L3, and the sections pass derivative rows and residuals between the team's caches
+		if (t > 8) t = 8;
 #endif
 		if (const char* e = std::getenv("PANO_BA_THREADS")) { const int v = std::atoi(e); if (v > 0) t = v; }
 		return t;
@@ -331,7 +333,10 @@ class IncrementalBundleAdjuster {
 				new_state.params = state.get_params();
 				for (size_t i = 0; i < new_state.params.size(); ++i)
 					if (i < idt * 6 + 3 || i >= idt * 6 + 6) new_state.params[i] -= update[i];     // R of the identity image stays
-				calcError(new_state, err_stat);        // (in place: the residuals of the previous trial were consumed by get_param_update above)
+				// (a FRESH residual vector per trial, on purpose: the team's threads have just read the previous one, and writing the new
+				// residuals over it meant invalidating every line in their caches -- 12 -> 23 ms of error statistic per estimate on the
+				// 256-CPU host -- while a new allocation has no sharers)
+				err_stat = calcError(new_state);
 				if (err_stat.avg >= best_err - 1e-3) { nr_non_decrease++; fresh = false; }
 				else { nr_non_decrease = 0; best_err = err_stat.avg; state = std::move(new_state); fresh = true; }
 				if (nr_non_decrease > 5) break;
