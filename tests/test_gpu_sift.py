@@ -331,3 +331,27 @@ def test_pipelined_host_call_equals_the_plain_call(ctx, cfg):
         if ref is not plain:
             ref.free()
     plain.free()
+
+
+def test_dense_extrema_fill_the_workgroup_lists(ctx, cfg):
+    """k_pyramid_rows collects a workgroup's raw extrema in a 192-entry LDS list and appends them to the image's list with one
+    atomic (csrc/pyramid.hip); further ones would go straight to the image's list.  Blurred noise is the densest field of DoG
+    extrema there is -- about one per fifty octave pixels and layer, i.e. up to ~115 in a 240 x 24 segment, so the overflow branch
+    is out of reach of the shipped Gaussian bank -- and a down-scaled noise image under a low PRE_COLOR_THRES fills the lists
+    to more than half (12 k raw extrema per image): every stage still equals the oracle's, raw lists included."""
+    from openpano_amd import hip
+    from openpano_amd.config import PanoConfig
+    from checkers import Oracle
+    rng = np.random.default_rng(12)
+    img = np.repeat(rng.random((900, 1300, 1), dtype=np.float32), 3, axis=2)
+    img = np.ascontiguousarray(0.25 + 0.5 * img)
+    loose = PanoConfig(PRE_COLOR_THRES=2e-3)
+    o = Oracle(loose).sift_stages(img)
+    h0, w0 = o.dims[0]
+    per_item = np.zeros(((h0 + 23) // 24, (w0 + 239) // 240), np.int64)
+    for s in range(1, 5):
+        xy = np.asarray(o.raw[(0, s)]).reshape(-1, 2)
+        np.add.at(per_item, (xy[:, 1] // 24, xy[:, 0] // 240), 1)
+    assert per_item.max() > 96 and sum(len(np.asarray(v).reshape(-1, 2)) for v in o.raw.values()) > 10000
+    g = hip.sift_staged(ctx, loose, img)
+    _compare_stages(g, o, loose)
