@@ -23,16 +23,16 @@ and RANSAC on a K_i*K_j-balanced share of the pair list, results gathered.  ``co
 BASELINE config 5 (128 x 4000x3000 uint8, 8128 pairs: the configuration whose per-GPU work stays large at N = 8)
 in the same line; under a weak headline ``strong_config4`` carries the strong-scaled config 4 next to it.
 
-The JSON line also carries
-  configs       BASELINE.json's other configurations, driver-timed in the same invocation (bench_configs.py): "2" (11 ordered
+The full record (every section below, with its prose) is written to bench_detail.json next to this file and under
+gpurun_out/; the ONE line on stdout is its scalar digest, capped at 6 KB (bench_line.py).  Sections of the record:
+  configs       BASELINE.json's other configurations, timed in the same invocation (bench_configs.py): "2" (11 ordered
                 600x400), "3" (13 ordered 1500x1112), "4_natural" (config 4 on the natural-texture crops SURVEY 8(d) names;
-                `value_natural` repeats its keypoints+descriptors/s next to `value`), each with its own parity block; "4" and
-                "5" are index entries pointing at the headline sections and at `config5`,
+                `value_natural` repeats its keypoints+descriptors/s next to `value`), each with its own parity block,
   roofline      live HIP-event timing of the dominant kernel vs its algorithmic HBM bytes,
   cpu_baseline  the reference's CPU path (oracle/_ref when it travelled, else the C oracle) timed
                 on this box's host cores on a bounded sample of the same images (rank 0, N=1),
   parity        the timed run's descriptors and match sets compared with the oracle (rank 0, N=1),
-  protocol      SURVEY 8(d)'s protocol number: pinned host Mat32f in -> descriptors D2H out.
+  protocol      SURVEY 8(d)'s protocol number: pinned host Mat32f in -> descriptors D2H out (`value_protocol_*`).
 """
 import argparse
 import json
@@ -739,7 +739,11 @@ def main():
         rp = os.path.join(ROOT, "profiles", "scale_rehearsal_latest.json")
         if os.path.exists(rp):
             try:
+                import hashlib
                 reh = json.load(open(rp))
+                if reh.get("_meta", {}).get("lib_sha256_16") != hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16]:
+                    log("profiles/scale_rehearsal_latest.json belongs to another build of the library: `predicted` dropped")
+                    reh = {}
                 for key, kind in (("strong_config4", "config4"), ("config5", "config5")):
                     pred = (reh.get(kind) or {}).get("worlds", {}).get(str(world))
                     if key in out and pred:
@@ -845,7 +849,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        real_stdout.write(json.dumps(out) + "\n")
+        # the full record goes to a side file; the line is the scalar digest of it, capped (bench_line.py)
+        import bench_line
+        detail = json.dumps(out)
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            try:
+                os.makedirs(d, exist_ok=True)
+                with open(os.path.join(d, bench_line.DETAIL_FILE), "w") as f:
+                    f.write(detail + "\n")
+            except OSError as e:
+                log(f"could not write {d}/{bench_line.DETAIL_FILE}: {e}")
+        real_stdout.write(bench_line.render(out) + "\n")
         real_stdout.flush()
     sys.exit(rc)
 

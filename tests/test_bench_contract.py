@@ -57,6 +57,60 @@ def test_cpu_baseline_leg_runs_and_reports_what_it_did(cfg):
     assert r["cpu_model"] and "best of 3" in r["sample"] and r["flags"]
 
 
+def _full_record():
+    """a real full record of an N = 1 run (round 5's 24.8 KB line, the one the driver could not parse)"""
+    import json
+    return json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_v6.json")).read().strip().splitlines()[-1])
+
+
+def test_bench_line_is_small_and_complete_at_one_gpu():
+    """the line bench.py prints = bench_line.render(full record): under the cap, every contract key, `roofline` and
+    `cpu_baseline` in the judged shape, consistent with the record it digests"""
+    import json
+    import bench_line
+    full = _full_record()
+    s = bench_line.render(full)
+    assert len(s) < bench_line.MAX_LINE_BYTES < 8192 and "\n" not in s
+    d = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert set(d["roofline"]) >= {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "host_cpus", "cpu_model"}
+    assert abs(d["value"] - full["value"]) < 1e-5 * full["value"] and abs(d["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert d["config5"]["match_roofline"]["frac"] and d["config5"]["parity"]["ok"] is True and d["parity"]["ok"] is True
+    assert d["value_protocol_f32"] and d["gpu_over_cpu_protocol_u8"] and d["detail"] == bench_line.DETAIL_FILE
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_line_stays_small_at_eight_gpus():
+    """a fabricated --gpus 8 record: rccl block, per-rank phase tables x 8 in config5 AND strong_config4, `predicted`
+    blocks, a long note -- everything the N > 1 code path adds (bench.py, bench_match.run_strong_job)"""
+    import copy
+    import json
+    import bench_line
+    full = _full_record()
+    full["n_gpus"] = 8; full["scaling"] = "strong"
+    full["rccl_ranks"] = {"world_size": 8, "allreduce_rank_sum": 36.0, "allreduce_count": 8, "expected_rank_sum": 36.0, "backend": "nccl", "ok": True}
+    full["config"]["note"] = "strong scaling of a 38-image job: " + "x" * 400
+    per_rank = [{"sift": 0.9 + r, "feature all-gather": 0.4, "match": 11.5, "ransac": 1.6, "results gather": 0.2} for r in range(8)]
+    for key in ("config5", "strong_config4"):
+        j = copy.deepcopy(full["config5"])
+        j["n_gpus"] = 8; j["per_rank_phase_ms"] = per_rank; j["allgather_bytes_per_rank"] = 33_000_000
+        j["predicted"] = {"phase_ms": dict(per_rank[0]), "job_ms": 25.1, "keypoints_per_s": 3.1e8, "image_pairs_per_s": 4.0e5, "source": "y" * 300}
+        full[key] = j
+    full["predicted"] = {"sift_ms_per_step": 0.27, "value": 1.7e8, "note": "z" * 200}
+    for k in ("cpu_baseline", "parity", "blend", "ingest", "protocol", "stitch_e2e", "configs"):   # rank 0 of N > 1 skips these legs
+        full.pop(k, None)
+    full["cpu_baseline"] = None; full["parity_checked"] = None
+    s = bench_line.render(full)
+    assert len(s) < bench_line.MAX_LINE_BYTES, len(s)
+    d = json.loads(s)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"]["world_size"] == 8 and d["rccl_ranks"]["ok"] is True
+    assert d["config5"]["max_rank_phase_ms"]["sift"] == 7.9 and "per_rank_phase_ms" not in d["config5"]
+    assert d["strong_config4"]["predicted"]["job_ms"] == 25.1 and d["roofline"]["frac"]
+    assert "x" * 50 not in s and "y" * 50 not in s and "z" * 50 not in s
+
+
 def test_committed_bench_lines_obey_the_contract():
     """The newest committed bench line of every round (profiles/rNN_bench_vM.json): contract keys, a roofline object
     that is consistent with itself (achieved = algorithmic bytes / launch time, frac = achieved / peak), parity
