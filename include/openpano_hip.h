@@ -273,8 +273,9 @@ void op_ransac_free(op_ransac_result* r);
  * becomes two directed entries -- pairwise_matches[i][j] = MatchInfo{confidence, homo (j -> i), matches (point in i, point
  * in j)} and pairwise_matches[j][i] = the same with homo.inverse() scaled by 1 / inv[8] and every match reversed
  * (match_info.hh:21-25) -- in the flat form pano_estimate_cameras (include/pano_host.h) takes: CameraEstimator's input
- * without a pass through the caller's own containers.  `pairs` / npairs are those of the op_ransac_pairs call that made r,
- * m the match lists it read.  Sizes first: entries = 2 x accepted pairs, points = total rows of pts.
+ * without a pass through the caller's own containers.  `pairs` / npairs MUST be those of the op_ransac_pairs call that made r,
+ * m the match lists it read (r keeps a hash of that pair list: another list is refused with OP_ERR_INVALID).  On any failure
+ * the output arrays may be partly written.  Sizes first: entries = 2 x accepted pairs, points = total rows of pts.
  *   ij      entries x 2        conf  entries        homo  entries x 9        cnt  entries
  *   pts     points x 4 (first.x, first.y, second.x, second.y), entries back to back */
 int op_pairwise_table_size(const op_ransac_result* r, int* entries, int64_t* points);
@@ -291,7 +292,11 @@ int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, co
  * projection method, proj_range.min, resolution and homo_inv per image.
  * Pixels are the reference's, bit for bit, for every projection (the map's sin / cos / tan are tabulated per canvas
  * column / row by the host libm, colour arithmetic is the reference's fp32 sequence); Color::NO = -1 marks
- * "no pixel" on input and output (lib/color.cc:11-15).
+ * "no pixel" on input and output (lib/color.cc:11-15).  "The host libm" is the one this library is linked against: the
+ * claim is bit-for-bit against a reference built on the same glibc (sin / cos / tan of other libms may differ in the last place).
+ * Threading: the tables are cached on the op_ctx (geometry key + host and device copy, (2 W + H) doubles each, for the
+ * context's lifetime).  Like every other per-context workspace they make an op_ctx THREAD-COMPATIBLE, not thread-safe:
+ * one call at a time per context; concurrent callers use one context each (as the adapters in pano_hip.hh do).
  * ===================================================================================== */
 typedef struct op_blend_image {
 	const float* data;    /* H x W x 3 fp32 (ImageRef::img, stitch/imageref.hh:15-17) */

@@ -51,7 +51,7 @@ struct DescLds {
 	unsigned long long mask[128];    // per bin: bit l = lane l's sample of the current batch contributes; after the scatter its first 512 bytes hold the batch's list records
 	float hist[128];                 // the keypoint's histogram (sift.cc:105): the running fp32 sum of every bin
 	unsigned short off[128];         // byte offset of every bin's first slot in sorted[]
-	unsigned q[QCAP];                // survivor queue (ring): window position (xx + 128) | (yy + 128) << 8
+	unsigned q[QCAP];                // survivor queue (ring): window position (xx + 32768) | (yy + 32768) << 16 (16 + 16 bits: any window radius)
 	uint64_t exptab[32];             // glibc's exp2f table (devmath.hpp), staged once per workgroup
 	unsigned long long startbits[COLCAP / 64];   // bit e: candidate e is the first of its window column
 	unsigned colpk[64];              // k-th non-empty window column: index of its first candidate << 16 | (first candidate row & 0xFF) << 8 | column
@@ -190,7 +190,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 				// the (columns started before the step + marks at or below e)-th listed column
 				const int start = incl - len;
 				const unsigned long long nonempty = __ballot(len > 0);
-				if (lane < COLCAP / 64) S.startbits[lane] = 0ULL;
+				// (the zero is made here: hoisted out of the keypoint loop as a register pair it was the one value the allocator
+				// spilled, and every keypoint then waited for a scratch load to clear sixteen words of LDS)
+				unsigned long long zero64 = 0ULL;
+				asm volatile("" : "+v"(zero64));
+				if (lane < COLCAP / 64) S.startbits[lane] = zero64;
 				WAVE_FENCE();
 				if (len > 0) {
 					atomicOr(&S.startbits[start >> 6], 1ULL << (start & 63));
@@ -401,8 +405,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DESC_WA
 			out[i] = sqrtf(v) * (float)p.desc_int_factor;
 		}
 		if (lane == 0) {   // feature/feature.cc:23-26
-			coor[kk * 2] = (kp.rx - 0.5) * (double)p.sw;
-			coor[kk * 2 + 1] = (kp.ry - 0.5) * (double)p.sh;
+			// (the two conversions are made here, per keypoint: as loop invariants they were register pairs held -- and spilled -- across the loop)
+			int sw = p.sw, sh = p.sh;
+			asm volatile("" : "+s"(sw), "+s"(sh));
+			coor[kk * 2] = (kp.rx - 0.5) * (double)sw;
+			coor[kk * 2 + 1] = (kp.ry - 0.5) * (double)sh;
 			real[kk * 2] = kp.rx; real[kk * 2 + 1] = kp.ry;      // do_detect_feature's own [0,1) output
 		}
 		WAVE_FENCE();

@@ -306,17 +306,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 	const float* Y = REV ? A : B;
 	const int ky = REV ? pd.ka : pd.kb;
 	const float* ny = S.norms + (REV ? pd.a_off : pd.b_off);
-	const int row = wk.rowblock * 128 + wave * 32 + j;
-	const int rowc = row < nrows ? row : nrows - 1;
-	// the X row: FWD a = rowc ; REV a = survivor, X = B[b*(a)]
-	const int a_row = REV ? S.surv[pd.res_off + rowc] : rowc;
-	const int x_idx = REV ? S.fb[pd.res_off + a_row] : a_row;
-	const float* X = (REV ? B : A) + (long long)x_idx * 128;
-	const uint4* XS = S.split + ((long long)(REV ? pd.b_off : pd.a_off) + x_idx) * 32;
+	// the X row: FWD a = row ; REV a = survivor, X = B[b*(a)].  Evaluated twice, from the thread index: here for the split
+	// fragments, and again behind the sweep for the epilogue (from an opaque copy of the index, so that the compiler
+	// recomputes the five values instead of parking them in scratch memory across the tile loop, whose registers are all taken)
+	auto x_row = [&](int tid_, int& row_, int& a_row_, int& x_idx_) {
+		row_ = wk.rowblock * 128 + (tid_ >> 6) * 32 + (tid_ & 31);
+		const int rowc = row_ < nrows ? row_ : nrows - 1;
+		a_row_ = REV ? S.surv[pd.res_off + rowc] : rowc;
+		x_idx_ = REV ? S.fb[pd.res_off + a_row_] : a_row_;
+	};
 	const uint4* YS = S.split + (long long)(REV ? pd.a_off : pd.b_off) * 32;
 	uint4 xh[8], xl[8];   // MFMA B operands: block kb covers k = 16 kb + 8 h .. + 7 of row j
+	{
+		int row0, a0, x0;
+		x_row(tid, row0, a0, x0);
+		const uint4* XS = S.split + ((long long)(REV ? pd.b_off : pd.a_off) + x0) * 32;
 #pragma unroll
-	for (int kb = 0; kb < 8; ++kb) { xh[kb] = XS[2 * kb + h]; xl[kb] = XS[16 + 2 * kb + h]; }
+		for (int kb = 0; kb < 8; ++kb) { xh[kb] = XS[2 * kb + h]; xl[kb] = XS[16 + 2 * kb + h]; }
+	}
 	// The X fragments must have LANDED before the tile loop: a load still pending at the loop header makes
 	// the compiler's wait-count pass put `s_waitcnt vmcnt(0/1)` in front of the MFMAs that read it in EVERY
 	// iteration.  Using the registers here forces the wait once, outside the loop.
@@ -407,6 +414,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 		tile_step(t, s_y0, s_y1, 0);
 		if (t + 1 < ntiles) tile_step(t + 1, s_y1, s_y0, 1);
 	}
+	int row, a_row, x_idx;
+	{
+		int tid2 = tid;
+		asm volatile("" : "+v"(tid2));
+		x_row(tid2, row, a_row, x_idx);
+	}
+	const float* X = (REV ? B : A) + (long long)x_idx * 128;
 	// (tile, slot) -> column: slot reg of lane half h is column (reg & 3) + 8 (reg >> 2) + 4 h of its tile; never-filled
 	// entries (tile -1) and the padded columns of the last tile (score -FLT_MAX, they rank above nothing real) are no candidates
 #pragma unroll
@@ -472,7 +486,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 #pragma unroll
 		for (int r = 0; r < NC; ++r) ccol = (cu == r) ? c[r] : ccol;
 		if (act) {
-			const f32x4* py = (const f32x4*)(Y + (long long)ccol * 128 + 64 * h);
+			// (scalar base + 32-bit lane offset: a per-lane 64-bit pointer Y + 64 h would be one more register pair held across the loop)
+			const f32x4* py = (const f32x4*)((const char*)Y + (unsigned)(ccol * 512 + 256 * h));
 #pragma unroll
 			for (int q = 0; q < 16; ++q) {      // static indices keep the row in VGPRs; 4 loads in flight at a time
 				const f32x4 b = py[q];
@@ -493,6 +508,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 		// hand the lower half's partial sums to the upper half (lane j -> lane j + 32)
 		v0 = __shfl(w0, j); v1 = __shfl(w1, j); v2 = __shfl(w2, j); v3 = __shfl(w3, j);
 	}
+	asm volatile("" : "+v"(a_row));        // the result addresses are formed HERE, not above the re-score loop (where they would be spilled)
 	if (h == 1 && live) {
 		if (overflow) {
 			int* q = REV ? S.slow_rev : S.slow_fwd;

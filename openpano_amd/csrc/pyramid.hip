@@ -69,8 +69,13 @@ __device__ __forceinline__ float third(float s) { return (float)((double)s * (1.
 
 constexpr int TR = 24, TC = 72;               // per-workgroup coordinate tables (rows, columns)
 
+#ifdef OP_GREY_WAVES            // A/B knob (scripts/build_variant.sh): resident wavefronts per SIMD the register allocation is held to
+#define OP_GREY_ATTR __attribute__((amdgpu_waves_per_eu(OP_GREY_WAVES, OP_GREY_WAVES)))
+#else
+#define OP_GREY_ATTR
+#endif
 template <typename SrcT>
-__global__ void __launch_bounds__(256) k_grey_octaves(SiftPlan p, int write_work) {
+__global__ void __launch_bounds__(256) OP_GREY_ATTR k_grey_octaves(SiftPlan p, int write_work) {
 	__shared__ float s_rgb[3][(WR + 1) * WP];
 	__shared__ float s_lut[256];
 	// resize_coord() is separable: the (source index, weight) of every row and of every column of the tile is computed
@@ -528,7 +533,13 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 constexpr int RW_OWN = OP_RW_OWN;     // columns owned by a band
 constexpr int RW_H = RW_OWN + 4;      // row-pass columns: x0 - 2 .. x0 + 241 (one ring column each side is used)
 constexpr int RW_QCAP = 1024;         // scan queue entries per row pair (overflow is handled in place)
-constexpr int RW_RAWCAP = 192;        // raw extrema a workgroup collects in LDS (x | y << 13 | layer << 26); more go straight to the image's list
+#ifndef OP_RW_RAWCAP                   // debug knobs of tests/test_gpu_sift.py (a variant build): a tiny LDS list / the unpackable path
+#define OP_RW_RAWCAP 192
+#endif
+#ifndef OP_RW_PACKABLE_BELOW
+#define OP_RW_PACKABLE_BELOW 8192
+#endif
+constexpr int RW_RAWCAP = OP_RW_RAWCAP;   // raw extrema a workgroup collects in LDS (x | y << 13 | layer << 26); more go straight to the image's list
 
 // wave64 inclusive add-scan on DPP (row_shr within the four rows of 16 lanes, then row_bcast:15 / :31 across rows);
 // call in wave-uniform control flow
@@ -675,7 +686,7 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 	const unsigned allow = (sc0 ? 0x0Fu : 0u) | (sc1 ? 0xF0u : 0u);
 	unsigned pm = 0;                                              // rr == 1: the gate mask of the row produced in the previous pair
 	if (tid < 2) { sQn[tid] = 0; sRawN[tid] = 0; }
-	const bool packable = od.w < 8192 && od.h < 8192;
+	const bool packable = od.w < OP_RW_PACKABLE_BELOW && od.h < OP_RW_PACKABLE_BELOW;
 	auto emit_raw = [&](int ex, int ey, int eL) {
 		int e = RW_RAWCAP;
 		if (packable) e = atomicAdd(&sRawN[0], 1);

@@ -45,7 +45,13 @@ struct op_ransac_result {
 		int best_count = -1, best_hyp = -1;
 	};
 	std::vector<Item> items;
+	uint64_t pairs_hash = 0;          // FNV-1a of the (i, j) list the result was computed for (op_pairwise_table checks its argument against it)
 };
+static uint64_t pair_list_hash(const int* pairs, int npairs) {
+	uint64_t h = 1469598103934665603ULL;
+	for (int k = 0; k < 2 * npairs; ++k) { h ^= (uint64_t)(uint32_t)pairs[k]; h *= 1099511628211ULL; }
+	return h;
+}
 
 // multi.hip: parts[k] holds the results of the pairs index[k][0..] -> one result in job order (parts are consumed)
 op_ransac_result* op_ransac_merge(op_ransac_result* const* parts, const std::vector<std::vector<int>>& index, int npairs) {
@@ -53,6 +59,7 @@ op_ransac_result* op_ransac_merge(op_ransac_result* const* parts, const std::vec
 	r->items.resize(npairs);
 	for (size_t k = 0; k < index.size(); ++k)
 		for (size_t q = 0; q < index[k].size(); ++q) r->items[index[k][q]] = std::move(parts[k]->items[q]);
+	r->pairs_hash = 0;                // a merged result is checked by its size only (the parts hashed their own sub-lists)
 	return r;
 }
 
@@ -574,6 +581,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	if (fv.device != ctx->device) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: the features live on another device than the context");
 	std::unique_ptr<op_ransac_result> R(new op_ransac_result);
 	R->items.resize(npairs);
+	R->pairs_hash = pair_list_hash(pairs, npairs);
 	if (npairs == 0) { *out = R.release(); return OP_OK; }
 	if (op_matches_num_pairs(mt) != npairs) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: op_matches holds a different number of pairs than the pair list");
 	const bool affine = cfg->CYLINDER || cfg->TRANS;                    // transform_estimate.cc:34-37
@@ -821,6 +829,9 @@ int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, co
 		int* ij, float* conf, double* homo, int* cnt, double* pts) {
 	if (!ctx || !f || !m || !r || !pairs || npairs != (int)r->items.size() || npairs != op_matches_num_pairs(m) || !ij || !conf || !homo || !cnt || !pts)
 		OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: bad argument");
+	if (r->pairs_hash && r->pairs_hash != pair_list_hash(pairs, npairs))
+		OP_FAIL(OP_ERR_INVALID, "op_pairwise_table: `pairs` is not the pair list the RANSAC result was computed for");
+	HIPCHK(hipSetDevice(ctx->device));
 	const FeatView fv = op_features_view(f);
 	const double* coor = op_features_coor_host(f, ctx);
 	const int* lists = op_matches_host(m);

@@ -671,7 +671,7 @@ def ransac_pairs_summary(ctx: Context, cfg, feats: Features, matches: Matches, p
     return ok.value, inl.value
 
 
-def ransac_pairwise_table(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0, seeds=None):
+def ransac_pairwise_table(ctx: Context, cfg, feats: Features, matches: Matches, pairs, shapes_wh, base_seed=0, seeds=None, table_pairs=None):
     """op_ransac_pairs + op_pairwise_table: RANSAC of every pair and Stitcher::match_image's bookkeeping (stitcher.cc:79-93)
     without unpacking a pair into Python.  -> (ij (E, 2) int32, conf (E,) float32, homo (E, 9) float64, cnt (E,) int32,
     pts (sum cnt, 4) float64, accepted pairs): the arguments of pano_estimate_cameras; E = 2 x accepted pairs."""
@@ -690,7 +690,8 @@ def ransac_pairwise_table(ctx: Context, cfg, feats: Features, matches: Matches, 
         E, P = ne.value, npt.value
         ij = np.zeros((max(E, 1), 2), np.int32); conf = np.zeros(max(E, 1), np.float32); homo = np.zeros((max(E, 1), 9), np.float64)
         cnt = np.zeros(max(E, 1), np.int32); pts = np.zeros((max(P, 1), 4), np.float64)
-        check(L.op_pairwise_table(ctx.handle, feats.handle, matches.handle, h, pr.ctypes.data_as(C.c_void_p), len(pr),
+        tp = pr if table_pairs is None else np.ascontiguousarray(np.asarray(table_pairs, np.int32).reshape(-1, 2))   # (tests: a list other than the call's is refused)
+        check(L.op_pairwise_table(ctx.handle, feats.handle, matches.handle, h, tp.ctypes.data_as(C.c_void_p), len(tp),
                                   ij.ctypes.data_as(C.c_void_p), conf.ctypes.data_as(C.c_void_p), homo.ctypes.data_as(C.c_void_p),
                                   cnt.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p)))
         return ij[:E], conf[:E], homo[:E], cnt[:E], pts[:P], E // 2

@@ -17,6 +17,9 @@
 #pragma once
 #ifdef _OPENMP
 #include <omp.h>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #endif
 #include <array>
 #include <atomic>
@@ -184,6 +187,12 @@ inline int ba_threads() {
 		// 52-56 ms, 24 threads 55-100 ms: eight cores share one L3, and the sections pass derivative rows and residuals between the team's caches
 		if (t > 8) t = 8;
 #endif
+#if defined(__linux__)
+		{	// never more spinning team members than CPUs this process may run on (taskset, cpuset cgroups)
+			cpu_set_t set;
+			if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && t > c) t = c; }
+		}
+#endif
 		if (const char* e = std::getenv("PANO_BA_THREADS")) { const int v = std::atoi(e); if (v > 0) t = v; }
 		return t;
 	}();
@@ -202,44 +211,58 @@ class BaTeam {
 		explicit BaTeam(int threads): nthreads(threads) {}
 		void set_threads(int t) { nthreads = t; }
 		int threads() const { return nthreads; }
-		// thread 0: run items 0..n-1 of f with the team; returns when all are done
+		// thread 0: run items 0..n-1 of f with the team; returns when all ITEMS are done -- not when every worker has
+		// checked in: a worker the OS has descheduled (fewer runnable CPUs than team members: a cgroup quota, taskset,
+		// several estimators at once) is not waited for, it finds the section over when it comes back
 		void run(int n_items, const std::function<void(int)>& f) {
 			if (nthreads <= 1 || n_items < 2) { for (int i = 0; i < n_items; ++i) f(i); return; }
-			fn = &f; n = n_items;
-			next.store(0, std::memory_order_relaxed); done.store(0, std::memory_order_relaxed);
-			epoch.fetch_add(1, std::memory_order_release);
-			work();
-			for (unsigned spins = 0; done.load(std::memory_order_acquire) != nthreads - 1; ++spins) relax(spins);
+			fn.store(&f, std::memory_order_relaxed); n.store(n_items, std::memory_order_relaxed);
+			done.store(0, std::memory_order_relaxed);
+			const unsigned long long e = ++section;
+			ticket.store(e << 32, std::memory_order_release);
+			work(e);
+			for (unsigned spins = 0; done.load(std::memory_order_acquire) != n_items; ++spins) relax(spins);
 		}
 		// threads 1..: until thread 0 calls finish()
 		void worker_loop() {
-			unsigned seen = 0;
+			unsigned long long seen = 0;
 			for (;;) {
-				unsigned e;
-				for (unsigned spins = 0; (e = epoch.load(std::memory_order_acquire)) == seen; ++spins) {
+				unsigned long long e;
+				for (unsigned spins = 0; (e = ticket.load(std::memory_order_acquire) >> 32) == seen; ++spins) {
 					if (quit.load(std::memory_order_acquire)) return;
 					relax(spins);
 				}
 				seen = e;
-				work();
-				done.fetch_add(1, std::memory_order_release);
+				work(e);
 			}
 		}
 		void finish() { quit.store(true, std::memory_order_release); }
 	private:
 		int nthreads;
-		std::atomic<unsigned> epoch{0};
-		std::atomic<int> next{0}, done{0};
+		unsigned long long section = 0;                      // thread 0 only
+		// (section << 32) | next item: an item is claimed by a compare-exchange on the pair, so a worker that wakes up in a
+		// later section can never take -- or lose -- one of ITS items with a stale function
+		std::atomic<unsigned long long> ticket{0};
+		std::atomic<int> done{0}, n{0};
 		std::atomic<bool> quit{false};
-		const std::function<void(int)>* fn = nullptr;
-		int n = 0;
-		void work() { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; (*fn)(i); } }
+		std::atomic<const std::function<void(int)>*> fn{nullptr};
+		void work(unsigned long long e) {
+			for (;;) {
+				unsigned long long t = ticket.load(std::memory_order_acquire);
+				if ((t >> 32) != e) return;
+				const int i = (int)(unsigned)t;
+				if (i >= n.load(std::memory_order_relaxed)) return;
+				if (!ticket.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+				(*fn.load(std::memory_order_relaxed))(i);        // the section cannot end (done != n) before this item has
+				done.fetch_add(1, std::memory_order_release);
+			}
+		}
 		// a pause per poll; on a host with fewer free cores than team members the waiters must not starve the thread they wait for
 		static void relax(unsigned spins) {
 #if defined(__x86_64__)
 			__builtin_ia32_pause();
 #endif
-			if ((spins & 0xFFFu) == 0xFFFu) std::this_thread::yield();
+			if ((spins & 0x3FFu) == 0x3FFu) std::this_thread::yield();
 		}
 };
 
@@ -418,15 +441,9 @@ class IncrementalBundleAdjuster {
 
 		std::vector<double> JtJ, Jtr;       // (6n)^2 and 6n, kept across iterations
 
+		// (a fresh result object per call, as in the reference: the LM loop keeps the accepted and the trial statistics side by side)
 		ErrorStats calcError(const ParamState& state) {            // :179-206
 			ErrorStats ret(nr_pointwise_match * NR_TERM_PER_MATCH);
-			calcError(state, ret);
-			return ret;
-		}
-		// the same into a caller-owned object: the LM loop computes ~250 of these per estimate, and a fresh 0.8-MB vector each time
-		// is an mmap, its page faults and a munmap (every residual is assigned below, nothing relies on the zero fill)
-		void calcError(const ParamState& state, ErrorStats& ret) {
-			ret.residuals.resize((size_t)nr_pointwise_match * NR_TERM_PER_MATCH);
 			const double t0 = ba_now();
 			auto cameras = state.get_cameras();
 			const int npairs = (int)match_pairs.size();
@@ -449,6 +466,7 @@ class IncrementalBundleAdjuster {
 			});
 			ret.update_stats(inlier_threshold);
 			ba_prof().t_err += ba_now() - t0;
+			return ret;
 		}
 
 		// (JtJ + damping) x = J^T r  (:231-251)
@@ -510,9 +528,10 @@ class IncrementalBundleAdjuster {
 			const int nr_img = (int)idx_added.size();
 			const int np = nr_img * NR_PARAM_PER_CAMERA;
 			if (!fresh) {              // same state as the previous call: the derivative rows and JtJ stand; J^T r with the new residuals
-				// (a camera's slice is three tasks of two parameters each: a well-connected camera walks thousands of matches, and
-				// one task per camera made the busiest camera the section's critical path; every entry's own chain is unchanged)
-				const int split = 1, rows = 6 / split;      // (a three-way split of a camera's parameters shortens the busiest camera's pass but reads every derivative row three times: 57 -> 67 ms per estimate on the 256-CPU host)
+				// one task per camera (split = 1).  A three-way split of a camera's six parameters (split = 3) shortens the busiest
+				// camera's pass but reads every derivative row three times: measured 57 -> 67 ms per estimate on the 256-CPU host,
+				// so it is not used; the constant stays so that the measurement can be repeated
+				const int split = 1, rows = 6 / split;
 				team_for(split * nr_img, [&](int task) {
 					const int c = task / split, a0 = rows * (task % split);
 					double g[6] = {0, 0, 0, 0, 0, 0};
@@ -601,9 +620,9 @@ class IncrementalBundleAdjuster {
 			});
 
 			// ---- phase 2: one task per 6 x 6 block (diagonal blocks also own their camera's J^T r slice)
-			// (a diagonal block is three tasks of two rows each -- rows a0, a0 + 1 of the block's upper triangle and the same two
-			// entries of J^T r: one task per camera made the best-connected camera the section's critical path)
-			const int split = 1, rows = 6 / split;         // (see above: splitting a diagonal block over tasks did not pay)
+			// (a diagonal block is ONE task -- rows 0..5 of the block's upper triangle and the camera's six entries of J^T r; see
+			// above: splitting it over three tasks did not pay)
+			const int split = 1, rows = 6 / split;
 			const int ndiag = split * nr_img, noff = (int)block_pairs.size();
 			team_for(ndiag + noff, [&](int task) {
 				if (task < ndiag) {

@@ -199,4 +199,7 @@ def test_pairwise_table_equals_match_image_bookkeeping(ctx, oracle, cfg):
         assert np.array_equal(pts[at + len(inl): at + 2 * len(inl)], np.concatenate([b, a], 1))
         at += 2 * len(inl); e += 2
     assert e == len(ij) == 2 * nconn and at == len(pts) and nconn >= 4
+    # the table is only defined for the pair list the result was computed for: a permuted list of the same length is refused
+    with pytest.raises(hip.OpenPanoHipError, match="not the pair list"):
+        hip.ransac_pairwise_table(ctx, cfg, f, mh, pairs, shapes, base_seed=42, table_pairs=pairs[::-1])
     mh.free(); f.free()

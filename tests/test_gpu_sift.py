@@ -355,3 +355,51 @@ def test_dense_extrema_fill_the_workgroup_lists(ctx, cfg):
     assert per_item.max() > 96 and sum(len(np.asarray(v).reshape(-1, 2)) for v in o.raw.values()) > 10000
     g = hip.sift_staged(ctx, loose, img)
     _compare_stages(g, o, loose)
+
+
+@pytest.mark.parametrize("flags", ["-DOP_RW_RAWCAP=4", "-DOP_RW_PACKABLE_BELOW=64"], ids=["lds-list-of-4", "unpackable"])
+def test_raw_extrema_overflow_branches_of_the_row_kernel(oracle, cfg, tmp_path, flags):
+    """k_pyramid_rows' emit_raw has two branches the shipped constants never reach: the workgroup's LDS list is
+    full (> 192 raw extrema in a 240 x 24 segment) and the octave is too large to pack a position into 26 bits (>= 8192 px).
+    Both then append straight to the image's list with a global atomic.  A variant of the library compiled with the knobs
+    of csrc/pyramid.hip -- an LDS list of FOUR entries / packing refused from 64 px -- runs the same two views in a
+    subprocess: descriptors and coordinates equal the oracle's."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    csrc = os.path.join(root, "openpano_amd", "csrc")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-I" + os.path.join(root, "include"), "-I" + csrc]
+    objs = []
+    jobs = []
+    for src in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
+        stem = os.path.basename(src)[:-4]
+        prebuilt = os.path.join(csrc, stem + ".o")
+        if stem != "pyramid" and os.path.exists(prebuilt):
+            objs.append(prebuilt)
+            continue
+        o = str(tmp_path / (stem + ".o"))
+        jobs.append(subprocess.Popen(base + ([flags] if stem == "pyramid" else []) + ["-c", src, "-o", o]))
+        objs.append(o)
+    assert all(j.wait() == 0 for j in jobs)
+    lib = str(tmp_path / "libopenpano_hip_variant.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", lib] + objs)
+    views = [_view(400, 600, 1), _view(300, 500, 5)]
+    np.savez(tmp_path / "in.npz", a=views[0], b=views[1])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from openpano_amd import hip\nfrom openpano_amd.config import PanoConfig\n"
+            "assert hip.LIB_PATH == %r\n"
+            "z = np.load(%r); c = hip.Context(0); out = {}\n"
+            "for k in ('a', 'b'):\n"
+            "    f = hip.sift_batch(c, PanoConfig(), [z[k]]); d, co = f.get(0); out[k + '_d'] = d; out[k + '_c'] = co; f.free()\n"
+            "np.savez(%r, **out); c.close()\n") % (root, lib, str(tmp_path / "in.npz"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, OPENPANO_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(tmp_path / "out.npz")
+    for k, im in zip("ab", views):
+        od, oc = oracle.detect_feature(im)
+        assert len(od) > 200 and np.array_equal(got[k + "_d"], od) and np.array_equal(got[k + "_c"], oc), k

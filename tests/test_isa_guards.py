@@ -100,3 +100,28 @@ def test_match_sweep_dma_wait_before_barrier(tmp_path):
             assert any(l.startswith("s_barrier") for l in nxt), (name, nxt[:12])
             upto = next(k for k, l in enumerate(nxt) if l.startswith("s_barrier"))
             assert not any(l.startswith(("buffer_", "global_", "flat_", "scratch_")) for l in nxt[:upto]), (name, nxt[:upto])
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Every kernel of the library keeps its state in registers and LDS: `ScratchSize [bytes/lane]` is 0 for all of them
+    (round 5 shipped 16 / 40 B/lane in k_match_sweep and 12 B/lane in k_descriptor -- a scratch reload sat inside the
+    candidate re-score loop and one in every keypoint of the descriptor kernel)."""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+
+    def usage(src):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+               "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        names = re.findall(r"Function Name: (\S+)", r.stderr)
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        assert len(names) == len(scratch), src          # (a host-only TU has no kernels)
+        return list(zip(names, scratch))
+
+    with ThreadPoolExecutor(4) as ex:
+        rows = [r for rs in ex.map(usage, sorted(glob.glob(os.path.join(CSRC, "*.hip")))) for r in rs]
+    assert len(rows) >= 40
+    assert not [r for r in rows if r[1] != 0], [r for r in rows if r[1] != 0]
