@@ -234,6 +234,9 @@ void op_ctx_destroy(op_ctx* c) {
 	resolve_profile(c);
 	for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
 	if (c->pinned) hipHostFree(c->pinned);
+	if (c->aux_stream) hipStreamDestroy(c->aux_stream);
+	if (c->aux_fork) hipEventDestroy(c->aux_fork);
+	if (c->aux_join) hipEventDestroy(c->aux_join);
 	if (c->h2d_stream) hipStreamDestroy(c->h2d_stream);
 	if (c->d2h_stream) hipStreamDestroy(c->d2h_stream);
 	if (c->owns_stream) hipStreamDestroy(c->stream);

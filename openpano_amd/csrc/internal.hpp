@@ -58,6 +58,15 @@ struct op_ctx {
 	} blend_trig, cyl_trig;
 	// copy streams of the host-image pipeline (op_sift_batch_host): uploads run ahead of the kernels, results leave behind them
 	hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+	// second compute stream of op_ransac_pairs (the pairs with few matches, whose sample tables take longest, run beside
+	// the others) and the two events that fork it from / join it to the context's stream
+	hipStream_t aux_stream = nullptr; hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+	hipError_t aux() {
+		if (!aux_stream) { hipError_t e = hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+		if (!aux_fork) { hipError_t e = hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming); if (e != hipSuccess) return e; }
+		if (!aux_join) { hipError_t e = hipEventCreateWithFlags(&aux_join, hipEventDisableTiming); if (e != hipSuccess) return e; }
+		return hipSuccess;
+	}
 	hipError_t copy_streams() {
 		if (!h2d_stream) { hipError_t e = hipStreamCreateWithFlags(&h2d_stream, hipStreamNonBlocking); if (e != hipSuccess) return e; }
 		if (!d2h_stream) { hipError_t e = hipStreamCreateWithFlags(&d2h_stream, hipStreamNonBlocking); if (e != hipSuccess) return e; }

@@ -17,6 +17,7 @@
 // the CPU path with the same seed.
 #include "internal.hpp"
 #include "ransac_math.hpp"
+#include "ransac_accept.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -37,6 +38,7 @@ const int* op_matches_host(const op_matches* m);
 const int* op_matches_device(const op_matches* m, int device, hipStream_t consumer);
 
 using opransac::P2;
+using opaccept::Shape; using opaccept::PointInPolygon; using opaccept::overlap_region; using opaccept::polygon_area; using opaccept::inverse3;
 
 struct op_ransac_result {
 	struct Item {
@@ -73,25 +75,20 @@ struct PairArgs {
 
 constexpr int RANSAC_PTS_CHUNK = 512;
 
-// The matched point pairs of every live image pair, gathered where both inputs already are: the match lists
-// op_match_pairs left in HBM and the keypoint coordinates of op_features (TransformEstimation's constructor
-// arguments, transform_estimate.cc:26-33: match.data[k] -> kp1[first], kp2[second]).  grid (ceil(max m / 256), live pairs)
-__global__ void __launch_bounds__(256) k_ransac_gather(const PairArgs* __restrict__ pairs, const int* __restrict__ active,
-		const int2* __restrict__ midx, const double2* __restrict__ coor, double* __restrict__ pts) {
-	const PairArgs pa = pairs[active[blockIdx.y]];
-	const int k = blockIdx.x * 256 + threadIdx.x;
-	if (k >= pa.m) return;
-	const int2 ab = midx[pa.moff + k];
-	const double2 p1 = coor[pa.off_i + ab.x], p2 = coor[pa.off_j + ab.y];
-	double2* o = (double2*)(pts + ((long long)pa.pts_off + k) * 4);
-	o[0] = p1; o[1] = p2;
-}
-
-// grid (ceil(iters/256), live pairs)
+// grid (ceil(iters/256), pairs of the launch's group); slot = slot_base + blockIdx.y is the pair's position in the live list.
+// One lane per hypothesis: 8-point (7 for affine) sample -> DLT -> health() -> inlier count over the pair's matches (staged in
+// LDS).  The winner -- the FIRST hypothesis with the maximal count (update_max, transform_estimate.cc:82) -- is chosen here as
+// well: every workgroup folds its 256 hypotheses into one 64-bit key (count + 1) << 32 | ~hypothesis and takes an atomic
+// maximum on the pair's word (zeroed by the pair's sample workgroup); the last of the pair's workgroups to finish (a counter)
+// decodes it and copies the winner's sample for the host epilogue.  No per-hypothesis counts in HBM, no selection kernel.
 __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__ pairs, const double* __restrict__ pts /* m x {p1x,p1y,p2x,p2y} */,
-		const unsigned short* __restrict__ samples, int iters, int* __restrict__ counts /* npairs x iters */, const int* __restrict__ active) {
+		const unsigned short* __restrict__ samples, int iters, const int* __restrict__ active, int slot_base,
+		unsigned long long* __restrict__ best64, int* __restrict__ done, int2* __restrict__ best, unsigned short* __restrict__ best_samp) {
 	__shared__ double s_pts[RANSAC_PTS_CHUNK * 4];
-	const int pair = active[blockIdx.y];
+	__shared__ unsigned long long s_key[4];
+	__shared__ int s_win;
+	const int slot = slot_base + blockIdx.y;
+	const int pair = active[slot];
 	const PairArgs pa = pairs[pair];
 	const int hyp = blockIdx.x * 256 + threadIdx.x;
 	const double* P = pts + (long long)pa.pts_off * 4;
@@ -117,7 +114,34 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(const PairArgs* __restrict__
 			for (int i = 0; i < cn; ++i)
 				cnt += opransac::is_inlier(H, P2{s_pts[4 * i], s_pts[4 * i + 1]}, P2{s_pts[4 * i + 2], s_pts[4 * i + 3]}, pa.inlier_dist) ? 1 : 0;
 	}
-	if (hyp < iters) counts[(long long)blockIdx.y * iters + hyp] = ok ? cnt : -1;      // per LIVE pair (slot blockIdx.y)
+	// larger count wins, then the smaller hypothesis index; a hypothesis that failed health() (or lies past iters) is key 0
+	unsigned long long key = (ok && hyp < iters) ? (((unsigned long long)(unsigned)(cnt + 1)) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)hyp) : 0ULL;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, off), hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), off);
+		const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+		key = o > key ? o : key;
+	}
+	if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long k = s_key[0];
+		for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k;
+		if (k) atomicMax(&best64[slot], k);
+		__threadfence();                                       // the maximum is in place before this workgroup counts as done
+		int win = -2;                                          // -2: not the pair's last workgroup
+		if (atomicAdd(&done[slot], 1) == (int)gridDim.x - 1) {
+			__threadfence();
+			const unsigned long long w = atomicMax(&best64[slot], 0ULL);      // (an atomic read: the other workgroups' maxima were made in L2)
+			win = w ? (int)(0xFFFFFFFFu - (unsigned)w) : -1;
+			best[slot] = make_int2(win, w ? (int)(unsigned)(w >> 32) - 1 : -1);
+		}
+		s_win = win;
+	}
+	__syncthreads();
+	const int win = s_win;
+	if (win != -2 && threadIdx.x < 8)      // the winner's sample, for the host epilogue
+		best_samp[slot * 8 + threadIdx.x] = win >= 0 ? samples[pa.samp_off + (long long)win * 8 + threadIdx.x] : (unsigned short)0;
 }
 
 // Sample tables: the std::mt19937 draw sequence of TransformEstimation::get_transform with its
@@ -299,29 +323,43 @@ __device__ __forceinline__ void rs_next_table(const unsigned short* rd, unsigned
 	}
 }
 
-// std::mt19937::seed for every pair at once (thread per pair; the recurrence is serial in i)
-__global__ void __launch_bounds__(64) k_ransac_seed(const unsigned* __restrict__ seeds, const int* __restrict__ active, int nactive, unsigned* __restrict__ state /* 624 x nactive */) {
-	const int q = blockIdx.x * 64 + threadIdx.x;
-	if (q >= nactive) return;
-	const int p = active[q];
-	unsigned v = seeds[p];
-	unsigned* st = state + q;                          // word-major: the lanes of a wavefront store to one cache line
-	st[0] = v;
-	for (int i = 1; i < 624; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i; st[(long long)i * nactive] = v; }
-}
-
-__global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ state,
-		int iters, unsigned short* __restrict__ samples, const int* __restrict__ active) {
+// One workgroup per live pair.  Before the table it (a) gathers the pair's matched points where both inputs already are --
+// the match lists op_match_pairs left in HBM and the keypoint coordinates of op_features (TransformEstimation's constructor
+// arguments, transform_estimate.cc:26-33: match.data[k] -> kp1[first], kp2[second]) -- for the hypothesis kernel and the host
+// epilogue, (b) clears the pair's winner word and finished-workgroups counter of the hypothesis kernel, and (c) seeds the
+// generator: std::mt19937::seed is a serial recurrence over 624 words, wave-uniform, i.e. scalar-unit work of wavefront 0
+// (~3 us) while the other wavefronts gather.  Rounds 1-5 ran (a) and (c) as two kernels of their own in front of this one.
+__global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restrict__ pairs, const unsigned* __restrict__ seeds,
+		int iters, unsigned short* __restrict__ samples, const int* __restrict__ active, int slot_base,
+		const int2* __restrict__ midx, const double2* __restrict__ coor, double* __restrict__ pts,
+		unsigned long long* __restrict__ best64, int* __restrict__ done) {
 	__shared__ unsigned mt[624];
 	__shared__ unsigned short rd[RS_N + 8];
 	__shared__ unsigned short Ja[RS_N + 2], Jb[RS_N + RS_W + 2];         // Jb doubles as the previous-equal table before the squaring starts
 	__shared__ unsigned short S[RS_SMAX];
 	__shared__ int s_cnt;
-	const int pair = active[blockIdx.x];               // only pairs with enough matches get a workgroup (the host compacts the list)
+	const int slot = slot_base + blockIdx.x;
+	const int pair = active[slot];                     // only pairs with enough matches get a workgroup (the host compacts the list)
 	const PairArgs pa = pairs[pair];
 	const int m = pa.m, ns = pa.nsample, tid = threadIdx.x;
+	if (tid == 0) { best64[slot] = 0ULL; done[slot] = 0; }
 	if (m < 8 || m < ns) return;                       // ESTIMATE_MIN_NR_MATCH (:21,39) / :55
-	for (int i = tid; i < 624; i += RS_T) mt[i] = state[(long long)i * gridDim.x + blockIdx.x];
+	if (tid < 64) {
+		unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)seeds[pair]);
+		if (tid == 0) mt[0] = v;
+		for (int i = 1; i < 624; ++i) {                 // wave-uniform chain: scalar registers; lane 0 stores
+			v = 1812433253u * (v ^ (v >> 30)) + (unsigned)i;
+			if (tid == 0) mt[i] = v;
+		}
+	} else {
+		for (int k = tid - 64; k < m; k += RS_T - 64) {
+			const int2 ab = midx[pa.moff + k];
+			const double2 p1 = coor[pa.off_i + ab.x], p2 = coor[pa.off_j + ab.y];
+			double2* o = (double2*)(pts + ((long long)pa.pts_off + k) * 4);
+			o[0] = p1; o[1] = p2;
+		}
+	}
+	__syncthreads();
 	unsigned short* sp = samples + pa.samp_off;
 	auto twist_word = [](unsigned hi, unsigned lo, unsigned far) {
 		const unsigned y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
@@ -419,145 +457,6 @@ __global__ void __launch_bounds__(RS_T) k_ransac_samples(const PairArgs* __restr
 	}
 }
 
-// first hypothesis with the maximal inlier count (update_max, transform_estimate.cc:82)
-__global__ void __launch_bounds__(256) k_ransac_best(const int* __restrict__ counts, int iters, int2* __restrict__ best,
-		const PairArgs* __restrict__ pairs, const unsigned short* __restrict__ samples, unsigned short* __restrict__ best_samp, const int* __restrict__ active) {
-	__shared__ int s_cnt[256], s_idx[256];
-	const int pair = active[blockIdx.x];
-	const int* c = counts + (long long)blockIdx.x * iters;
-	int bc = -1, bi = -1;
-	for (int i = threadIdx.x; i < iters; i += 256) { const int v = c[i]; if (v > bc) { bc = v; bi = i; } }
-	s_cnt[threadIdx.x] = bc; s_idx[threadIdx.x] = bi;
-	__syncthreads();
-	for (int st = 128; st > 0; st >>= 1) {
-		if (threadIdx.x < st) {
-			const int oc = s_cnt[threadIdx.x + st], oi = s_idx[threadIdx.x + st];
-			if (oc > s_cnt[threadIdx.x] || (oc == s_cnt[threadIdx.x] && oc >= 0 && oi < s_idx[threadIdx.x])) { s_cnt[threadIdx.x] = oc; s_idx[threadIdx.x] = oi; }
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) best[blockIdx.x] = make_int2(s_idx[0], s_cnt[0]);          // results are stored per live slot
-	if (threadIdx.x < 8) {     // the winner's sample, for the host epilogue
-		const int bi0 = s_idx[0];
-		best_samp[blockIdx.x * 8 + threadIdx.x] = bi0 >= 0 ? samples[pairs[pair].samp_off + (long long)bi0 * 8 + threadIdx.x] : (unsigned short)0;
-	}
-}
-
-// ---------------- host epilogue: fill_inliers_to_matchinfo and its helpers ----------------
-struct Shape { int w, h; };
-inline bool shifted_in(const Shape& s, P2 p) {        // match_info.hh:68-70
-	return p.x >= -s.w * 0.5 && p.x < s.w * 0.5 && p.y >= -s.h * 0.5 && p.y < s.h * 0.5;
-}
-inline double side(P2 a, P2 b, P2 p) { return (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x); }   // polygon.cc:9-11
-
-std::vector<P2> convex_hull(std::vector<P2>& pts) {  // lib/polygon.cc:17-46
-	if (pts.size() <= 3) return pts;
-	std::sort(pts.begin(), pts.end(), [](const P2& a, const P2& b) { if (a.y == b.y) return a.x < b.x; return a.y < b.y; });
-	std::vector<P2> ret;
-	ret.push_back(pts[0]); ret.push_back(pts[1]);
-	const int n = (int)pts.size();
-	for (int i = 2; i < n; ++i) {
-		while (ret.size() >= 2 && side(ret[ret.size() - 2], ret.back(), pts[i]) <= 0) ret.pop_back();
-		ret.push_back(pts[i]);
-	}
-	const size_t mid = ret.size();
-	ret.push_back(pts[n - 2]);
-	for (int i = n - 3; i >= 0; --i) {
-		while (ret.size() > mid && side(ret[ret.size() - 2], ret.back(), pts[i]) <= 0) ret.pop_back();
-		ret.push_back(pts[i]);
-	}
-	return ret;
-}
-
-double polygon_area(const std::vector<P2>& poly) {   // lib/polygon.cc:48-60
-	const int n = (int)poly.size();
-	double sum = 0;
-	for (int i = 0; i < n; ++i) sum += poly[i].x * (poly[(i + 1) % n].y - poly[(i + n - 1) % n].y);
-	return 0.5 * std::fabs(sum);
-}
-
-struct PointInPolygon {                               // lib/polygon.hh:30-52, polygon.cc:62-82
-	const std::vector<P2>& poly; P2 com; std::vector<std::pair<float, int>> slopes;
-	explicit PointInPolygon(const std::vector<P2>& p): poly(p) {
-		com = P2{0, 0};
-		for (auto& c : poly) { com.x += c.x; com.y += c.y; }
-		const double f = 1.0 / poly.size();
-		com.x *= f; com.y *= f;
-		for (size_t i = 0; i < p.size(); ++i) slopes.emplace_back((float)std::atan2(p[i].y - com.y, p[i].x - com.x), (int)i);
-		std::sort(slopes.begin(), slopes.end());
-	}
-	bool in_polygon(P2 p) const {
-		const float k = (float)std::atan2(p.y - com.y, p.x - com.x);
-		auto itr = std::lower_bound(slopes.begin(), slopes.end(), std::make_pair(k, 0));
-		int idx1, idx2;
-		if (itr == slopes.end()) { idx1 = slopes.back().second; idx2 = slopes.front().second; }
-		else { idx2 = itr->second; idx1 = (itr != slopes.begin()) ? (--itr)->second : slopes.back().second; }
-		const P2 p1 = poly[idx1], p2 = poly[idx2];
-		const double o1 = side(p1, p2, com), o2 = side(p1, p2, p);
-		return !(o1 * o2 < -1e-6);
-	}
-};
-
-inline P2 trans2d(const double (&H)[9], P2 m) {       // homography.hh:53-76
-	const double x = H[0] * m.x + H[1] * m.y + H[2] * 1.0, y = H[3] * m.x + H[4] * m.y + H[5] * 1.0, z = H[6] * m.x + H[7] * m.y + H[8] * 1.0;
-	const double d = 1.0 / z;
-	return P2{x * d, y * d};
-}
-
-// 3x3 inverse with complete pivoting (Homography::inverse, stitch/homography.cc:25-39)
-bool inverse3(const double (&a)[9], double (&inv)[9]) {
-	double lu[9]; std::memcpy(lu, a, sizeof(lu));
-	int rowt[3], colt[3], nonzero = 3; double maxpivot = 0;
-	for (int k = 0; k < 3; ++k) {
-		int br = k, bc = k; double best = -1;
-		for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j) { double v = std::fabs(lu[i * 3 + j]); if (v > best) { best = v; br = i; bc = j; } }
-		if (best == 0.0) { nonzero = k; for (int i = k; i < 3; ++i) rowt[i] = colt[i] = i; break; }
-		if (best > maxpivot) maxpivot = best;
-		rowt[k] = br; colt[k] = bc;
-		if (br != k) for (int j = 0; j < 3; ++j) std::swap(lu[k * 3 + j], lu[br * 3 + j]);
-		if (bc != k) for (int i = 0; i < 3; ++i) std::swap(lu[i * 3 + k], lu[i * 3 + bc]);
-		for (int i = k + 1; i < 3; ++i) lu[i * 3 + k] /= lu[k * 3 + k];
-		for (int i = k + 1; i < 3; ++i) for (int j = k + 1; j < 3; ++j) lu[i * 3 + j] -= lu[i * 3 + k] * lu[k * 3 + j];
-	}
-	const double thr = std::fabs(maxpivot) * (2.220446049250313e-16 * 3);
-	int rank = 0;
-	for (int i = 0; i < nonzero; ++i) rank += (std::fabs(lu[i * 3 + i]) > thr);
-	if (rank != 3) return false;
-	for (int col = 0; col < 3; ++col) {
-		double c[3];
-		for (int i = 0; i < 3; ++i) c[i] = (i == col) ? 1.0 : 0.0;
-		for (int i = 0; i < 3; ++i) std::swap(c[i], c[rowt[i]]);
-		for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) c[i] -= lu[i * 3 + j] * c[j];
-		for (int i = 2; i >= 0; --i) { for (int j = i + 1; j < 3; ++j) c[i] -= lu[i * 3 + j] * c[j]; c[i] /= lu[i * 3 + i]; }
-		for (int i = 2; i >= 0; --i) std::swap(c[i], c[colt[i]]);
-		for (int i = 0; i < 3; ++i) inv[i * 3 + col] = c[i];
-	}
-	return true;
-}
-
-// overlap_region (stitch/homography.cc:50-90): homo maps shape2 -> shape1, inv the reverse
-std::vector<P2> overlap_region(const Shape& shape1, const Shape& shape2, const double (&homo)[9], const double (&inv)[9]) {
-	const int NR = 100;
-	const float stepw = (float)(shape2.w * 1.0 / NR), steph = (float)(shape2.h * 1.0 / NR);
-	const double hw = shape2.w * 0.5, hh = shape2.h * 0.5;
-	std::vector<P2> pts2in1;
-	for (int i = 0; i < NR; ++i) {
-		const P2 e[4] = { P2{-hw + i * stepw, -hh}, P2{-hw + i * stepw, hh}, P2{-hw, -hh + i * steph}, P2{hw, -hh + i * steph} };
-		for (int k = 0; k < 4; ++k) {
-			// Matrix product 3x3 * 3x(4 NR) then float denom = 1.0 / z (:72-76)
-			const double x = homo[0] * e[k].x + homo[1] * e[k].y + homo[2] * 1.0;
-			const double y = homo[3] * e[k].x + homo[4] * e[k].y + homo[5] * 1.0;
-			const double z = homo[6] * e[k].x + homo[7] * e[k].y + homo[8] * 1.0;
-			const float denom = (float)(1.0 / z);
-			const P2 pin1{x * denom, y * denom};
-			if (shifted_in(shape1, pin1)) pts2in1.push_back(pin1);
-		}
-	}
-	const P2 corners[4] = { P2{-shape1.w * 0.5, -shape1.h * 0.5}, P2{shape1.w * 0.5, -shape1.h * 0.5}, P2{-shape1.w * 0.5, shape1.h * 0.5}, P2{shape1.w * 0.5, shape1.h * 0.5} };
-	for (auto& c : corners) if (shifted_in(shape2, trans2d(inv, c))) pts2in1.push_back(c);
-	return convex_hull(pts2in1);
-}
-
 struct PairHost {
 	int i, j, m, slot;             // slot: index among the live pairs (-1: below the match-count gate)
 	const double* kp1; int nk1;    // image i keypoints (x, y) centred
@@ -602,8 +501,8 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 
 	// pass 1: what the kernels need per pair -- counts and offsets only, no coordinates, no lists
 	std::vector<PairHost> ph(npairs);
-	std::vector<int> h_active;
-	long long pts_total = 0; int max_m = 0;
+	std::vector<int> h_active, order;
+	long long pts_total = 0;
 	for (int p = 0; p < npairs; ++p) {
 		const int i = pairs[2 * p], j = pairs[2 * p + 1];
 		if (i < 0 || j < 0 || i >= fv.n || j >= fv.n) OP_FAIL(OP_ERR_INVALID, "op_ransac_pairs: image index out of range");
@@ -625,15 +524,25 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		const float thres = (float)((h.s1.w + h.s1.h) * 0.5 / 800 * cfg->RANSAC_INLIER_THRES);
 		h.inlier_dist = (double)(thres * thres);
 		if (h.m >= 8 && h.m >= nsample) {                                  // ESTIMATE_MIN_NR_MATCH (:21,39) / :55: otherwise get_transform -> false
-			h.slot = (int)h_active.size(); h_active.push_back(p); pts_total += h.m; max_m = std::max(max_m, h.m);
+			h.slot = 0; h_active.push_back(p); pts_total += h.m;
 		}
 	}
 	const int nactive = (int)h_active.size();
 	if (nactive == 0) { *out = R.release(); return OP_OK; }
+	// The live list in two groups, each with launches of its own on a stream of its own.  A sample is the first `nsample`
+	// DISTINCT draws: at m = 8 a hypothesis consumes 21.7 draws on average, at m = 13 11.7, from m = 16 on about 10 -- the
+	// sample table of a pair with few matches takes twice as long as the others' (and most candidate pairs of an unordered
+	// job have few: median 13 on config 4).  With one launch per stage every pair's hypotheses waited for the slowest table;
+	// now the hypotheses of the many-matches group run under the tail of the few-matches group's tables.
+	const int small_m = 14;                                               // m < small_m: the few-matches group (second in the list)
+	std::stable_partition(h_active.begin(), h_active.end(), [&](int p) { return ph[p].m >= small_m; });
+	int n_large = 0;
+	for (int q = 0; q < nactive; ++q) { ph[h_active[q]].slot = q; n_large += ph[h_active[q]].m >= small_m ? 1 : 0; }
+	const int n_small = nactive - n_large;
 
 	// One device arena (the context's grow-only RANSAC scratch) and one pinned block: [PairArgs | seeds | live list |
 	// the match lists if they only exist on the host] go up in one copy, [winner | its sample | gathered points] come
-	// back in one copy.  Samples, generator states and hypothesis counts exist per LIVE pair only.
+	// back in one copy.  Sample tables and the winner words exist per LIVE pair only.
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
 	const int* d_midx_resident = op_matches_device(mt, ctx->device, st);
 	const bool upload_lists = !d_midx_resident && mtotal > 0;
@@ -642,20 +551,20 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	const size_t r_best = 0, r_bsamp = al(r_best + sizeof(int2) * nactive), r_pts = al(r_bsamp + sizeof(unsigned short) * 8 * nactive),
 			down_bytes = al(r_pts + sizeof(double) * 4 * (size_t)pts_total);
 	const size_t o_up = 0, o_down = al(o_up + up_bytes), o_samp = al(o_down + down_bytes),
-			o_state = al(o_samp + sizeof(unsigned short) * 8 * (size_t)nactive * iters),
-			o_counts = al(o_state + sizeof(unsigned) * 624 * (size_t)nactive),
-			arena_bytes = al(o_counts + sizeof(int) * (size_t)nactive * iters);
+			o_best64 = al(o_samp + sizeof(unsigned short) * 8 * (size_t)nactive * iters),
+			o_done = al(o_best64 + sizeof(unsigned long long) * (size_t)nactive),
+			arena_bytes = al(o_done + sizeof(int) * (size_t)nactive);
 	char* pin = (char*)ctx->pinned_scratch(up_bytes + down_bytes);
 	if (!pin) OP_FAIL(OP_ERR_HIP, "op_ransac_pairs: pinned host allocation failed");
 	{
 		PairArgs* pa = (PairArgs*)(pin + u_pa);
 		unsigned* h_seeds = (unsigned*)(pin + u_seeds);
-		long long pts_off = 0;
+		std::vector<long long> slot_pts(nactive + 1, 0);                   // gathered points lie in live-list order
+		for (int q = 0; q < nactive; ++q) slot_pts[q + 1] = slot_pts[q] + ph[h_active[q]].m;
 		for (int p = 0; p < npairs; ++p) {
 			const PairHost& h = ph[p];
-			pa[p] = PairArgs{(int)pts_off, h.m, affine ? 1 : 0, nsample, h.inlier_dist, (long long)std::max(h.slot, 0) * iters * 8,
+			pa[p] = PairArgs{h.slot >= 0 ? (int)slot_pts[h.slot] : 0, h.m, affine ? 1 : 0, nsample, h.inlier_dist, (long long)std::max(h.slot, 0) * iters * 8,
 					(long long)moffset[p], (int)fv.offsets[h.i], (int)fv.offsets[h.j]};
-			if (h.slot >= 0) pts_off += h.m;
 			// per-pair seeds; the draw sequence itself is generated on the device (k_ransac_samples)
 			h_seeds[p] = seeds ? seeds[p] : (base_seed * 2654435761u) ^ (uint32_t)(p * 40503u + 12345u);
 		}
@@ -683,27 +592,31 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		unsigned short* d_bsamp = (unsigned short*)(arena + o_down + r_bsamp);
 		double* d_pts = (double*)(arena + o_down + r_pts);
 		unsigned short* d_samp = (unsigned short*)(arena + o_samp);
-		unsigned* d_state = (unsigned*)(arena + o_state);
-		int* d_counts = (int*)(arena + o_counts);
+		unsigned long long* d_best64 = (unsigned long long*)(arena + o_best64);
+		int* d_done = (int*)(arena + o_done);
+		const double2* d_coor = (const double2*)op_features_coor_device(f);
+		const dim3 hyp_x((iters + 255) / 256);
 		RCHK(hipMemcpyAsync(arena + o_up, pin, up_bytes, hipMemcpyHostToDevice, st));
+		// pairs below the match-count gate never get a workgroup: launching groups that exit at once costs more
+		// dispatcher time than the live ones compute (config 4: 703 pairs, ~640 live)
+		auto launch_group = [&](hipStream_t s, int slot_base, int n) {
+			hipLaunchKernelGGL(k_ransac_samples, dim3(n), dim3(RS_T), 0, s, d_pa, d_seeds, iters, d_samp, d_active, slot_base, d_midx, d_coor, d_pts, d_best64, d_done);
+			hipLaunchKernelGGL(k_ransac_hyp, dim3(hyp_x.x, n), dim3(256), 0, s, d_pa, (const double*)d_pts, (const unsigned short*)d_samp, iters, d_active, slot_base,
+					d_best64, d_done, d_best, d_bsamp);
+			return hipGetLastError();
+		};
 		{
-			ProfScope ps2(ctx, "ransac mt19937 samples");
-			// pairs below the match-count gate never get a workgroup: launching groups that exit at once costs more
-			// dispatcher time than the live ones compute (config 4: 703 pairs, ~640 live)
-			hipLaunchKernelGGL(k_ransac_seed, dim3((nactive + 63) / 64), dim3(64), 0, st, d_seeds, d_active, nactive, d_state);
-			RCHK(hipGetLastError());
-			hipLaunchKernelGGL(k_ransac_samples, dim3(nactive), dim3(RS_T), 0, st, d_pa, (const unsigned*)d_state, iters, d_samp, d_active);
-			RCHK(hipGetLastError());
-		}
-		{
-			ProfScope ps(ctx, "ransac hypotheses");
-			hipLaunchKernelGGL(k_ransac_gather, dim3((max_m + 255) / 256, nactive), dim3(256), 0, st, d_pa, d_active, d_midx,
-					(const double2*)op_features_coor_device(f), d_pts);
-			RCHK(hipGetLastError());
-			hipLaunchKernelGGL(k_ransac_hyp, dim3((iters + 255) / 256, nactive), dim3(256), 0, st, d_pa, (const double*)d_pts, (const unsigned short*)d_samp, iters, d_counts, d_active);
-			RCHK(hipGetLastError());
-			hipLaunchKernelGGL(k_ransac_best, dim3(nactive), dim3(256), 0, st, (const int*)d_counts, iters, d_best, d_pa, (const unsigned short*)d_samp, d_bsamp, d_active);
-			RCHK(hipGetLastError());
+			ProfScope ps(ctx, "ransac kernels (both streams)");
+			const bool fork = n_small > 0 && n_large > 0;
+			if (fork) {
+				RCHK(ctx->aux());
+				RCHK(hipEventRecord(ctx->aux_fork, st));                     // the upload (and whatever made the inputs) is in front of both groups
+				RCHK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+				RCHK(launch_group(ctx->aux_stream, n_large, n_small));       // the long tables first
+				RCHK(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+				RCHK(launch_group(st, 0, n_large));
+				RCHK(hipStreamWaitEvent(st, ctx->aux_join, 0));
+			} else RCHK(launch_group(st, 0, nactive));
 		}
 		RCHK(hipMemcpyAsync(pin + up_bytes, arena + o_down, down_bytes, hipMemcpyDeviceToHost, st));
 		// the acceptance gates count the keypoints of both images inside the overlap polygon (:191-199): every
@@ -724,10 +637,15 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 	}
 
 	// ---- host epilogue per pair (transform_estimate.cc:85-86, 150-218) ----
-	host_parallel_for(npairs, [&](int p) {
+	// live pairs only (the others stay at get_transform -> false, :55), longest match lists first: a pair that passes the
+	// first gates counts the keypoints of both images against the overlap polygons (~70 us), most pairs end after a few
+	// microseconds -- dealt in list order the long ones landed at the end of somebody's queue.
+	order = h_active;
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ph[a].m > ph[b].m; });
+	host_parallel_for(nactive, [&](int q) {
+		const int p = order[q];
 		op_ransac_result::Item& it = R->items[p];
 		const PairHost& h = ph[p];
-		if (h.slot < 0) return;                                                       // get_transform -> false (:55)
 		it.best_hyp = best[h.slot].x; it.best_count = best[h.slot].y;
 		if (it.best_hyp < 0 || it.best_count < 0) return;
 		const unsigned short* sp = best_samp + (size_t)h.slot * 8;

@@ -4,7 +4,7 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["OPENPANO_HIP_LIB"] = os.path.join(ROOT, "openpano_amd", "variants", "libopenpano_hip_rs9.so")
+os.environ["OPENPANO_HIP_LIB"] = os.path.join(ROOT, "ab", "libopenpano_hip_rs9.so")
 import numpy as np
 from openpano_amd import hip, synth
 from openpano_amd.config import PanoConfig
