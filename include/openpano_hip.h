@@ -294,7 +294,7 @@ int op_pairwise_table(op_ctx* ctx, const op_features* f, const op_matches* m, co
  * column / row by the host libm, colour arithmetic is the reference's fp32 sequence); Color::NO = -1 marks
  * "no pixel" on input and output (lib/color.cc:11-15).  "The host libm" is the one this library is linked against: the
  * claim is bit-for-bit against a reference built on the same glibc (sin / cos / tan of other libms may differ in the last place).
- * Threading: the tables are cached on the op_ctx (geometry key + host and device copy, (2 W + H) doubles each, for the
+ * Threading: the tables are cached per context -- geometry key + host and device copy, (2 W + H) doubles each, for the
  * context's lifetime).  Like every other per-context workspace they make an op_ctx THREAD-COMPATIBLE, not thread-safe:
  * one call at a time per context; concurrent callers use one context each (as the adapters in pano_hip.hh do).
  * ===================================================================================== */

@@ -440,7 +440,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 	// Only a half whose four entries ALL sit inside the margin sends the row to the exact full scan (four
 	// near-ties in one half: an order of magnitude rarer than four in the row).
 	const float gmax = __uint_as_float(*S.gmax_bits);
-	const float E = 8.2e-5f * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);   // 8e-5 for the MFMA scores + 2 * 2^-20 for the keys' slot bits
+#ifndef OP_MATCH_MARGIN
+#define OP_MATCH_MARGIN 8.2e-5f      // 8e-5 for the MFMA scores + 2 * 2^-20 for the keys' slot bits
+#endif
+	const float E = OP_MATCH_MARGIN * (S.norms[(REV ? pd.b_off : pd.a_off) + x_idx] + gmax);
 	const float* ms = s_ms[wave][j][0]; const int* mi = s_mi[wave][j][0];            // [half][NK] contiguous
 	const float second = fmaxf(fminf(ms[0], ms[NK]), fmaxf(ms[1], ms[NK + 1]));      // 2nd largest key of the row (invalid entries rank below every real one)
 	const float thr = second - E;
