@@ -11,6 +11,7 @@
 #     + the record the test writes itself, tied to the library's hash -> config5_all_pairs.json (copy to profiles/config5_all_pairs_latest.json)
 #   9 one-device rehearsal of the 1 / 2 / 4 / 8-rank strong-scaled jobs, config 4 and config 5 (scripts/scale_rehearsal.py)
 #     -> <tag>_scale_rehearsal.json (copy to profiles/scale_rehearsal_latest.json: bench.py --gpus N prints it as `predicted`)
+#  10 per-dispatch matrix-pipe counters of the config-5 sweeps -> <tag>_config5_mfma.json (copy to profiles/config5_mfma_latest.json)
 # Usage: scripts/gpu_evidence.sh <tag> [sections, default "1 2 3 4 5 6 7"]
 tag=${1:-r05}; what=${2:-"1 2 3 4 5 6 7"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -62,6 +63,11 @@ fi
 if has 9; then
   ( timeout 600 python scripts/scale_rehearsal.py ${tag} ) > gpurun_out/${tag}_rehearsal.txt 2>&1
   tail -3 gpurun_out/${tag}_rehearsal.txt
+fi
+if has 10; then      # per-dispatch matrix-pipe counters of the config-5 sweeps -> <tag>_config5_mfma.json (copy to profiles/config5_mfma_latest.json)
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_pmc_c5mfma -o pmc -- \
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-blend --no-ingest --no-configs > gpurun_out/${tag}_pmc_c5mfma.json 2> gpurun_out/${tag}_pmc_c5mfma.err
+  python scripts/pmc_config5_mfma.py gpurun_out/${tag}_pmc_c5mfma gpurun_out/${tag}_config5_mfma.json | tail -30
 fi
 python - <<PY
 import json
