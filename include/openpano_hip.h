@@ -207,6 +207,10 @@ const int* op_matches_device_list(const op_matches* m);
 int64_t op_matches_total(const op_matches* m);
 /* wrap host match lists (npairs lists of counts[p] <first, second> pairs): debug / test entry */
 int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npairs, op_matches** out);
+/* a's pairs followed by b's as ONE result (both made with contexts of ctx's device): what a rank of a sharded job passes to
+ * op_ransac_pairs when it matched its pair list in two calls (stitcher.cc:100-113 is one loop over all pairs).  The new
+ * object owns a copy of the lists; a and b stay valid and are freed by the caller. */
+int op_matches_concat(op_ctx* ctx, const op_matches* a, const op_matches* b, op_matches** out);
 void op_matches_free(op_matches* m);
 
 /* =====================================================================================

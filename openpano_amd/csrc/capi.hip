@@ -183,7 +183,7 @@ int op_ctx_profile_get(op_ctx* c, int i, const char** label, double* total_ms, l
 }
 
 const char* op_last_error(void) { return g_last_error.c_str(); }
-int op_abi_version(void) { return 7; }      // 3: op_blend_image.mat_h / mat_w; 4: resident match lists, op_sift_batch_host, op_ransac_pairs_multi; 5: op_ctx_profile_only; 6: op_debug_set_desc_list_cap; 7: op_pairwise_table
+int op_abi_version(void) { return 8; }      // 8: op_matches_concat; 3: op_blend_image.mat_h / mat_w; 4: resident match lists, op_sift_batch_host, op_ransac_pairs_multi; 5: op_ctx_profile_only; 6: op_debug_set_desc_list_cap; 7: op_pairwise_table
 
 void op_config_default(op_config* c) {
 	// src/config.cfg (every literal goes through a float, lib/config.cc:19-26)

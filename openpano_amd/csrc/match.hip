@@ -908,6 +908,49 @@ int op_matches_from_host(const int* const* idx_pairs, const int* counts, int npa
 	return OP_OK;
 }
 
+// Two results of op_match_pairs on ONE device as one: the pairs of a, then the pairs of b, lists back to back in a new device
+// buffer (two device-to-device copies on the context's stream).  A rank of a sharded job matches the pairs of two own images
+// while the other ranks' features travel and the rest afterwards -- two op_matches; joined, its RANSAC stage is ONE
+// op_ransac_pairs call instead of two (the call's latency does not depend on the pair count: DESIGN section 6).
+// The indices keep their meaning: they count keypoints inside an image, whichever feature table holds it.
+int op_matches_concat(op_ctx* ctx, const op_matches* a, const op_matches* b, op_matches** out) {
+	if (!ctx || !a || !b || !out) OP_FAIL(OP_ERR_INVALID, "op_matches_concat: bad argument");
+	if (!a->parts.empty() || !b->parts.empty()) OP_FAIL(OP_ERR_UNSUPPORTED, "op_matches_concat: results of a device group cannot be joined");
+	HIPCHK(hipSetDevice(ctx->device));
+	std::unique_ptr<op_matches> m(new op_matches);
+	m->npairs = a->npairs + b->npairs;
+	m->count = a->count; m->count.insert(m->count.end(), b->count.begin(), b->count.end());
+	m->offset.assign(m->npairs + 1, 0);
+	for (int p = 0; p < m->npairs; ++p) m->offset[p + 1] = m->offset[p] + m->count[p];
+	m->total = m->offset[m->npairs];
+	if (!a->lim.empty() && !b->lim.empty()) { m->lim = a->lim; m->lim.insert(m->lim.end(), b->lim.begin(), b->lim.end()); }
+	m->device = ctx->device; m->stream = ctx->stream;
+	const bool resident = (a->total == 0 || (a->d_idx && a->device == ctx->device)) && (b->total == 0 || (b->d_idx && b->device == ctx->device));
+	if (resident && m->total) {
+		if (a->total && a->stream != ctx->stream) HIPCHK(hipStreamSynchronize(a->stream));     // the per-pair sort that fills a list is only ordered on its own stream
+		if (b->total && b->stream != ctx->stream) HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(pool_alloc((void**)&m->d_idx, sizeof(int) * 2 * (size_t)m->total));
+		if (a->total) HIPCHK(hipMemcpyAsync(m->d_idx, a->d_idx, sizeof(int) * 2 * (size_t)a->total, hipMemcpyDeviceToDevice, ctx->stream));
+		if (b->total) HIPCHK(hipMemcpyAsync(m->d_idx + 2 * a->total, b->d_idx, sizeof(int) * 2 * (size_t)b->total, hipMemcpyDeviceToDevice, ctx->stream));
+		HIPCHK(hipEventCreateWithFlags(&m->produced, hipEventDisableTiming));
+		HIPCHK(hipEventRecord(m->produced, ctx->stream));
+	}
+	// the host mirror comes along when both sides already have theirs (a job that gathers its lists has fetched them)
+	bool both_host;
+	{ std::lock_guard<std::mutex> la(a->mu); both_host = a->host_valid; }
+	{ std::lock_guard<std::mutex> lb(b->mu); both_host = both_host && b->host_valid; }
+	if (both_host || !resident) {
+		const int* ha = op_matches_host(a); const int* hb = op_matches_host(b);
+		if (!ha || !hb) return OP_ERR_HIP;
+		m->h_idx.resize((size_t)std::max<int64_t>(m->total, 1) * 2);
+		if (a->total) std::memcpy(m->h_idx.data(), ha, sizeof(int) * 2 * (size_t)a->total);
+		if (b->total) std::memcpy(m->h_idx.data() + 2 * a->total, hb, sizeof(int) * 2 * (size_t)b->total);
+		m->host_valid = true;
+	}
+	*out = m.release();
+	return OP_OK;
+}
+
 int op_matches_count(const op_matches* m, int p) { return (m && p >= 0 && p < m->npairs) ? m->count[p] : 0; }
 int op_matches_copy(const op_matches* m, int p, int* idx_pairs) {
 	if (!m || p < 0 || p >= m->npairs || !idx_pairs) OP_FAIL(OP_ERR_INVALID, "op_matches_copy: bad argument");

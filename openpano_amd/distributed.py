@@ -266,6 +266,10 @@ class HipEngine:
         """op_ransac_pairs without unpacking every pair into Python -> (accepted pairs, inliers)"""
         return self.hip.ransac_pairs_summary(self.ctx, self.cfg, table, mh, pairs, shapes_wh, seeds=seeds)
 
+    def concat(self, mh_a, mh_b):
+        """two match handles of this device as one (a's pairs, then b's): one RANSAC call instead of two"""
+        return self.hip.Matches.concat(self.ctx, mh_a, mh_b)
+
     def free(self, obj):
         obj.free()
 
@@ -416,11 +420,31 @@ class ShardedJob:
     def seeds(self, base_seed):
         return [(int(base_seed) + i * self.n + j) & 0xFFFFFFFF for i, j in self.my_pairs]
 
+    def _joined(self):
+        """The pairs matched during the exchange (on this rank's own features) and the rest (on the exchanged table) as ONE
+        list on the exchanged table -- it holds the own images too, keypoint for keypoint, so the own pairs' match lists
+        index it as they are -- behind one match handle: op_ransac_pairs costs about the same for 11 pairs as for 88, and a
+        rank paid it twice.  -> (order of my_pairs indices, joined handle or None when one call covers everything anyway)"""
+        rest = self._rest()
+        if not rest or not self.local_sel or not hasattr(self.e, "concat"):
+            return None, None
+        return rest + list(self.local_sel), self.e.concat(self.mh, self.local_mh)
+
     def ransac(self, shapes_wh, base_seed=1):
         """shapes_wh: (w, h) per image id"""
         seeds = self.seeds(base_seed)
         rest = self._rest()
         out = [None] * len(self.my_pairs)
+        order, joined = self._joined()
+        if joined is not None:
+            try:
+                rr = self.e.ransac(self.tab, joined, [self.lists[k] for k in order], [self.my_pairs[k] for k in order], shapes_wh, [seeds[k] for k in order])
+            finally:
+                self.e.free(joined)
+            for k, r in zip(order, rr):
+                out[k] = r
+            self.rres = out
+            return sum(1 for r in self.rres if r["ok"])
         if rest:
             rr = self.e.ransac(self.tab, self.mh, [self.lists[k] for k in rest], [self.my_pairs[k] for k in rest], shapes_wh, [seeds[k] for k in rest])
             for k, r in zip(rest, rr):
@@ -437,6 +461,12 @@ class ShardedJob:
         """RANSAC over this rank's pairs without unpacking every pair into Python (HipEngine) -> (accepted pairs, inliers)"""
         seeds = self.seeds(base_seed)
         rest = self._rest()
+        order, joined = self._joined()
+        if joined is not None:
+            try:
+                return self.e.ransac_summary(self.tab, joined, [self.my_pairs[k] for k in order], shapes_wh, [seeds[k] for k in order])
+            finally:
+                self.e.free(joined)
         ok = inl = 0
         if rest:
             a, b = self.e.ransac_summary(self.tab, self.mh, [self.my_pairs[k] for k in rest], shapes_wh, [seeds[k] for k in rest])

@@ -169,6 +169,8 @@ def lib():
         L.op_ransac_pairs_multi.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.op_matches_from_host.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    if hasattr(L, "op_matches_concat"):
+        L.op_matches_concat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     L.op_ransac_pairs.argtypes = [C.c_void_p, C.POINTER(OpConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.op_ransac_ok.argtypes = [C.c_void_p, C.c_int]
@@ -599,6 +601,13 @@ class Matches:
         h = C.c_void_p()
         check(lib().op_matches_from_host(ptrs, counts, n, C.byref(h)))
         return cls(h, n)
+
+    @classmethod
+    def concat(cls, ctx, a, b):
+        """a's pairs followed by b's as one handle (op_matches_concat): one op_ransac_pairs call for both"""
+        h = C.c_void_p()
+        check(lib().op_matches_concat(ctx.handle, a.handle, b.handle, C.byref(h)))
+        return cls(h, a.npairs + b.npairs)
 
     def free(self):
         if self.handle:

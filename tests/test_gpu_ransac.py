@@ -203,3 +203,34 @@ def test_pairwise_table_equals_match_image_bookkeeping(ctx, oracle, cfg):
     with pytest.raises(hip.OpenPanoHipError, match="not the pair list"):
         hip.ransac_pairwise_table(ctx, cfg, f, mh, pairs, shapes, base_seed=42, table_pairs=pairs[::-1])
     mh.free(); f.free()
+
+
+def test_joined_match_handles_give_the_single_call_results(ctx, cfg):
+    """op_matches_concat: a pair list matched in two calls and joined == the list matched in one call -- the lists, and every
+    pair's RANSAC result through ONE op_ransac_pairs call on the joined handle (what a rank of a sharded job does with the
+    pairs it matched during the exchange and the rest: openpano_amd/distributed.py)."""
+    from openpano_amd import hip
+    n = 6
+    views = synth.image_set(n, 400, 600, seed=31, overlap=0.45)
+    f = hip.sift_batch(ctx, cfg, views)
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    shapes = [(600, 400)] * n
+    seeds = [1000 + 7 * k for k in range(len(pairs))]
+    whole = hip.match_pairs_handle(ctx, cfg, f, pairs)
+    want_lists = whole.lists()
+    want = hip.ransac_pairs(ctx, cfg, f, whole, pairs, shapes, seeds=seeds)
+    cut = 4
+    a = hip.match_pairs_handle(ctx, cfg, f, pairs[:cut]); b = hip.match_pairs_handle(ctx, cfg, f, pairs[cut:])
+    for fetch_first in (False, True):            # with and without host mirrors on the two sides
+        if fetch_first:
+            a.lists(); b.lists()
+        j = hip.Matches.concat(ctx, a, b)
+        got_lists = j.lists()
+        assert len(got_lists) == len(pairs) and all(np.array_equal(g, w) for g, w in zip(got_lists, want_lists))
+        got = hip.ransac_pairs(ctx, cfg, f, j, pairs, shapes, seeds=seeds)
+        for g, w in zip(got, want):
+            assert g["ok"] == w["ok"] and g["best_hyp"] == w["best_hyp"] and g["best_count"] == w["best_count"]
+            assert np.array_equal(g["homo"], w["homo"]) and np.array_equal(g["inliers"], w["inliers"]) and g["confidence"] == w["confidence"]
+        j.free()
+    assert sum(1 for w in want if w["ok"]) >= 3
+    a.free(); b.free(); whole.free(); f.free()
