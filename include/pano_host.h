@@ -20,6 +20,9 @@ extern "C" {
 /* namespace config values read by the host stages (lib/config.hh): STRAIGHTEN, MULTIPASS_BA,
  * LM_LAMBDA (+ ESTIMATE_CAMERA, ORDERED_INPUT, TRANS, CYLINDER).  Returns 0, or -1 for an unknown key. */
 int pano_config_set(const char* key, float value);
+/* the K_i * K_j-balanced pair deal of a sharded job (stitcher.cc:100's pair list over the ranks): own pairs
+ * first, the rest longest first to the least-loaded rank; mine[k] = 1 for the pairs of `rank`; owner may be NULL */
+int pano_deal_pairs(int npairs, const int* pairs, const long long* cost, int world, int rank, const int* owner, int nimg, unsigned char* mine);
 
 /* Stitcher::estimate_camera's CameraEstimator{pairwise_matches, shapes}.estimate().
  *   n            images; shapes_wh: n x (w, h)

@@ -79,6 +79,52 @@ def all_pairs(n: int):
     return [(i, j) for i in range(n) for j in range(i + 1, n)]
 
 
+_HOST_LIB = None
+
+
+def _host_lib():
+    """libpano_host.so (host-only C, no HIP) when it is built, else False: the deal below then runs in Python"""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpano_host.so")
+        try:
+            L = C.CDLL(path)
+            L.pano_deal_pairs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+            _HOST_LIB = L
+        except (OSError, AttributeError):
+            _HOST_LIB = False
+    return _HOST_LIB
+
+
+def _deal_native(pairs, rank, world, counts, blocks):
+    """partition_pairs' balanced deal in C (pano_deal_pairs, host/pano_host_capi.cc): the same deal, item for item
+    (tests/test_distributed_cpu.py compares the two), at microseconds instead of the 6-19 ms the loop below takes for the
+    8128 pairs of a 128-image job -- on every rank, inside every exchange.  None when the library is not there."""
+    L = _host_lib()
+    if not L or not pairs:
+        return None
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    cnt = np.asarray(counts, np.int64)
+    nimg = len(cnt)
+    if pr.min() < 0 or pr.max() >= nimg:
+        return None
+    cost = np.ascontiguousarray(cnt[pr[:, 0]] * cnt[pr[:, 1]])
+    owner = None
+    if blocks is not None:
+        owner = np.full(nimg, -1, np.int32)
+        for r, b in enumerate(blocks):
+            for g in b:
+                if 0 <= g < nimg:
+                    owner[g] = r
+    mine = np.zeros(len(pr), np.uint8)
+    rc = L.pano_deal_pairs(len(pr), pr.ctypes.data, cost.ctypes.data, world, rank, owner.ctypes.data if owner is not None else None, nimg, mine.ctypes.data)
+    if rc != 0:
+        return None
+    return sorted(pairs[k] for k in np.flatnonzero(mine))
+
+
 def partition_pairs(pairs, rank: int, world: int, counts=None, blocks=None):
     """Deal pairs to ranks.  With ``counts`` the deal is balanced by K_i*K_j (longest first,
     greedy); without, plain round-robin.  Deterministic and identical on every rank.
@@ -86,6 +132,9 @@ def partition_pairs(pairs, rank: int, world: int, counts=None, blocks=None):
     it can be matched while the feature exchange is still in flight -- and the rest is dealt on top of that load."""
     if counts is None:
         return pairs[rank::world]
+    dealt = _deal_native(pairs, rank, world, counts, blocks)
+    if dealt is not None:
+        return dealt
     cost = [counts[i] * counts[j] for i, j in pairs]
     load = [0] * world
     mine = []

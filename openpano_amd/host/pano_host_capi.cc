@@ -2,6 +2,7 @@
 // callers that are not C++ (tests/test_camera_*.py through ctypes; any FFI).  Host-only: built
 // with g++ into openpano_amd/libpano_host.so, no HIP.  Signatures mirror oracle/ref_driver.cc's
 // ref_estimate_cameras so that the parity tests feed both sides the same arrays.
+#include <algorithm>
 #include <vector>
 
 #include "pano_camera.hh"
@@ -13,6 +14,32 @@ using namespace pano;
 // those names (the hooked CLI, oracle/ref_stitch_test) -- exported, the two sets would interpose each other.
 #pragma GCC visibility push(default)
 extern "C" {
+
+// The pair deal of a sharded job (openpano_amd/distributed.py: partition_pairs): pairs whose two images one rank owns go to
+// that rank first (they are matched while the features travel), the rest is dealt longest first (cost K_i * K_j, ties by
+// position in the list) to the rank with the least load so far (ties: the lower rank).  Deterministic, identical on every
+// rank; mine[k] = 1 for the pairs of `rank`.  Plain host code: at 8128 pairs the Python loop it replaces took 6-19 ms of
+// every exchange, more than a rank's share of the SIFT phase.  owner[g] = rank that owns image g, or -1; may be null.
+int pano_deal_pairs(int npairs, const int* pairs, const long long* cost, int world, int rank, const int* owner, int nimg, unsigned char* mine) {
+	if (npairs < 0 || world <= 0 || rank < 0 || rank >= world || (npairs && (!pairs || !cost || !mine))) return -1;
+	std::vector<long long> load(world, 0);
+	std::vector<int> rest; rest.reserve(npairs);
+	for (int k = 0; k < npairs; ++k) {
+		mine[k] = 0;
+		const int i = pairs[2 * k], j = pairs[2 * k + 1];
+		const int oi = (owner && i >= 0 && i < nimg) ? owner[i] : -1, oj = (owner && j >= 0 && j < nimg) ? owner[j] : -1;
+		if (oi >= 0 && oi == oj && oi < world) { load[oi] += cost[k]; if (oi == rank) mine[k] = 1; }
+		else rest.push_back(k);
+	}
+	std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+	for (int k : rest) {
+		int r = 0;
+		for (int q = 1; q < world; ++q) if (load[q] < load[r]) r = q;
+		load[r] += cost[k];
+		if (r == rank) mine[k] = 1;
+	}
+	return 0;
+}
 
 int pano_config_set(const char* key, float v) {
 	const std::string k(key);

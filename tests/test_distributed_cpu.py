@@ -229,3 +229,34 @@ def test_rehearsal_mode_equals_single_rank(world):
             assert np.array_equal(r["inliers"], w["inliers"]) and np.array_equal(r["homo"], w["homo"], equal_nan=True), (rank, p)
         job.close()
     assert sorted(seen) == all_pairs(n)
+
+
+def test_native_pair_deal_equals_the_python_deal():
+    """partition_pairs' balanced deal runs in C when libpano_host.so is built (pano_deal_pairs: the Python loop took
+    6-19 ms for the 8128 pairs of a 128-image job, inside every rank's exchange): same deal, item for item, for every
+    rank, with and without the own-pairs-first blocks, on ragged keypoint counts incl. empty images."""
+    import numpy as np
+    from openpano_amd import distributed as D
+    if not D._host_lib():
+        import pytest
+        pytest.skip("libpano_host.so not built")
+    rng = np.random.default_rng(5)
+    native = D._HOST_LIB
+    try:
+        for n, world in ((38, 8), (38, 2), (128, 8), (11, 3), (7, 4), (5, 8), (2, 2)):
+            counts = [int(x) for x in rng.integers(0, 5000, n)]
+            counts[rng.integers(0, n)] = 0
+            blocks = [D.shard_images(n, r, world) for r in range(world)]
+            pairs = D.all_pairs(n)
+            seen = []
+            for rank in range(world):
+                for bl in (None, blocks):
+                    D._HOST_LIB = native
+                    a = D.partition_pairs(pairs, rank, world, counts, bl)
+                    D._HOST_LIB = False
+                    b = D.partition_pairs(pairs, rank, world, counts, bl)
+                    assert a == b, (n, world, rank, bl is not None)
+                seen += a
+            assert sorted(seen) == pairs            # every pair dealt exactly once
+    finally:
+        D._HOST_LIB = native
