@@ -155,6 +155,7 @@ struct SiftPlan {
 	// two sigmas (2 pl + 1, 2 pl + 2) that share one packed accumulator; a shorter kernel is
 	// zero-extended (adding +-0 leaves an fp32 sum unchanged, so the padding is exact).
 	int rows_ok;
+	int rw_seg;                 // rows of a segment (chosen per batch: the launch should be a whole number of device fills, sift_host.hip)
 	int rw_items;               // work items per image: sum over octaves of bands x segments
 	float kpair[3][7][2];
 	// thresholds
@@ -180,9 +181,10 @@ struct KeyPoint {
 
 #define OP_DESC_LIST_CAP 640   // k_descriptor: floats in the list arena of one batch's counting sort
 #define OP_RW_OWN 240     // k_pyramid_rows: columns owned by a band
-#ifndef OP_RW_SEG
-#define OP_RW_SEG 24      // rows of a segment
-#endif
+// rows of a segment: chosen per batch between OP_RW_SEG_MIN and OP_RW_SEG_MAX (a build with -DOP_RW_SEG=<rows> pins it: A/B runs)
+#define OP_RW_SEG_DEFAULT 24
+#define OP_RW_SEG_MIN 16
+#define OP_RW_SEG_MAX 40
 #define OP_PYR_TW 64
 #ifndef OP_PYR_TH
 #define OP_PYR_TH 16

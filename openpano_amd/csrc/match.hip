@@ -499,7 +499,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MATCH_
 				d = xf[q].y - b.y; w1 += d * d;
 				d = xf[q].z - b.z; w2 += d * d;
 				d = xf[q].w - b.w; w3 += d * d;
-				if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#ifndef OP_MATCH_RESCORE_INFLIGHT
+#define OP_MATCH_RESCORE_INFLIGHT 4
+#endif
+				if ((q & (OP_MATCH_RESCORE_INFLIGHT - 1)) == OP_MATCH_RESCORE_INFLIGHT - 1) __builtin_amdgcn_sched_barrier(0);
 			}
 		}
 		if (h == 1 && act) {

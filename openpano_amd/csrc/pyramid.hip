@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256) k_pyramid(SiftPlan p, int* __restrict__ r
 }
 
 // ---- K3r: the same stage as K3, row-streaming form for the shipped Gaussian bank ---------------
-// A 256-thread workgroup owns a band of RW_OWN columns x OP_RW_SEG rows of one octave and walks down the
+// A 256-thread workgroup owns a band of RW_OWN columns x p.rw_seg rows of one octave and walks down the
 // rows two at a time; nothing but two rows of column-pass results and four rows of DoG live in LDS.
 //   column pass: thread = column.  It keeps the 14 grey rows around the current row pair in
 //     registers (a sliding window fed by one coalesced load per row) and accumulates all six sigmas
@@ -618,8 +618,8 @@ __global__ void __launch_bounds__(256) k_pyramid_rows(SiftPlan p, int* __restric
 		item -= cnt; ++o;
 	}
 	const OctDesc od = p.oct[o];
-	const int x0 = (item % od.rw_nb) * RW_OWN, y0 = (item / od.rw_nb) * OP_RW_SEG;
-	const int rows_own = od.h - y0 < OP_RW_SEG ? od.h - y0 : OP_RW_SEG;
+	const int x0 = (item % od.rw_nb) * RW_OWN, y0 = (item / od.rw_nb) * p.rw_seg;
+	const int rows_own = od.h - y0 < p.rw_seg ? od.h - y0 : p.rw_seg;
 	const int nsteps = (rows_own + 3) >> 1;                       // row pairs (y0-1, y0), ... covering y0-1 .. y0+rows_own
 	float* ws = p.ws + (long long)img * p.ws_stride;
 	const float* grey = ws + plane_off_grey(od);

@@ -149,7 +149,7 @@ int build_gauss_bank(const op_config& cfg, SiftPlan& p) {
 	return 0;
 }
 
-int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
+int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p, int num_cu = 256) {
 	memset(&p, 0, sizeof(p));
 	if (cfg.NUM_OCTAVE < 1 || cfg.NUM_OCTAVE > OP_MAX_OCT || cfg.NUM_SCALE < 4 || cfg.NUM_SCALE > OP_MAX_SCALE)
 		OP_FAIL(OP_ERR_UNSUPPORTED, "NUM_OCTAVE must be in [1,8] and NUM_SCALE in [4,12]");
@@ -182,15 +182,45 @@ int build_plan(const op_config& cfg, int n, int sh, int sw, SiftPlan& p) {
 		p.rows_ok = p.nscale == 7;
 		for (int s = 1; s < 7 && p.rows_ok; ++s) if (p.kcenter[s] != shipped[s - 1]) p.rows_ok = 0;
 		if (p.rows_ok) {
-			// work items of k_pyramid_rows: bands of OP_RW_OWN columns x segments of OP_RW_SEG rows.
+			// work items of k_pyramid_rows: bands of OP_RW_OWN columns x segments of rw_seg rows.
 			// Every segment re-reads 14 halo rows and adds three rows of redundant passes; long segments pay in ramp-up
-			// and tail (a workgroup's lifetime grows with the segment).  Measured on config 4 with the kernel as it is
-			// now (VALU-bound: 6 planes out): 16 rows 0.392 ms, 24 rows 0.382, 32 rows 0.394.
+			// and tail (a workgroup's lifetime grows with the segment).  On a large batch the height hardly matters
+			// (config 4, 38 images = 8 fills of the device: 20 / 24 / 28 / 40 / 48 rows = 0.376 / 0.374 / 0.373 / 0.371 / 0.376 ms,
+			// profiles/r06_sift_seg.txt).  On a small one it decides how many times the device is filled: four workgroups
+			// fit a CU (LDS), and 5 images at 24 rows are 1065 workgroups on 1024 places -- 41 of them run alone behind the
+			// rest and the kernel takes two workgroup lifetimes instead of one.  So the height is chosen per batch: the one
+			// that minimises (fills of the device, rounded up) x (a workgroup's steps at that height).
+			auto items_at = [&](int seg) {
+				long long it = 0;
+				for (int i = 0; i < p.noct; ++i) it += (long long)((p.oct[i].w + OP_RW_OWN - 1) / OP_RW_OWN) * ((p.oct[i].h + seg - 1) / seg);
+				return it;
+			};
+			int seg = OP_RW_SEG_DEFAULT;
+#ifdef OP_RW_SEG
+			seg = OP_RW_SEG;
+#else
+			{
+				const long long places = (long long)(num_cu > 0 ? num_cu : 256) * 4;
+				auto cost_at = [&](int c) {
+					const long long items = items_at(c) * n;
+					const long long fills = (items + places - 1) / places;
+					return (double)fills * ((c + 3) / 2 + 1.2);       // steps of a workgroup: row pairs + the 14-row window fill (~1.2 steps)
+				};
+				const double dflt = cost_at(OP_RW_SEG_DEFAULT);
+				double best = dflt;
+				for (int c = OP_RW_SEG_MIN; c <= OP_RW_SEG_MAX; c += 2) {
+					const double cost = cost_at(c);
+					if (cost < best) { best = cost; seg = c; }
+				}
+				if (best > 0.93 * dflt) seg = OP_RW_SEG_DEFAULT;       // the model is coarse: only a clear win moves the height (measured: equal within 1 % on 8 fills)
+			}
+#endif
+			p.rw_seg = seg;
 			p.rw_items = 0;
 			for (int i = 0; i < p.noct; ++i) {
 				OctDesc& o = p.oct[i];
 				o.rw_nb = (o.w + OP_RW_OWN - 1) / OP_RW_OWN;
-				o.rw_nseg = (o.h + OP_RW_SEG - 1) / OP_RW_SEG;
+				o.rw_nseg = (o.h + seg - 1) / seg;
 				p.rw_items += o.rw_nb * o.rw_nseg;
 			}
 		}
@@ -222,7 +252,7 @@ int run_group(op_ctx* ctx, const op_config& cfg, const std::vector<const op_imag
 		SiftPlan& plan, GroupResult& res, op_sift_dump* keep) {
 	const int n = (int)imgs.size();
 	const int sh = imgs[0]->h, sw = imgs[0]->w;
-	int rc = build_plan(cfg, n, sh, sw, plan);
+	int rc = build_plan(cfg, n, sh, sw, plan, ctx->num_cu);
 	if (rc != OP_OK) return rc;
 	hipStream_t st = ctx->stream;
 	// per-image capacity of the raw / refined lists: speculative like capK below.  The kernels clamp
