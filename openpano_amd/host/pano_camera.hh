@@ -216,19 +216,19 @@ class BaTeam {
 		// several estimators at once) is not waited for, it finds the section over when it comes back
 		void run(int n_items, const std::function<void(int)>& f) {
 			if (nthreads <= 1 || n_items < 2) { for (int i = 0; i < n_items; ++i) f(i); return; }
-			fn.store(&f, std::memory_order_relaxed); n.store(n_items, std::memory_order_relaxed);
-			done.store(0, std::memory_order_relaxed);
-			const unsigned long long e = ++section;
-			ticket.store(e << 32, std::memory_order_release);
-			work(e);
-			for (unsigned spins = 0; done.load(std::memory_order_acquire) != n_items; ++spins) relax(spins);
+			for (int base = 0; base < n_items; base += MAX_ITEMS) {       // (a section holds < 2^20 items: the count rides in the ticket)
+				const int cnt = std::min(n_items - base, (int)MAX_ITEMS);
+				if (base == 0 && cnt == n_items) { run_section(cnt, f); break; }
+				const std::function<void(int)> g = [&f, base](int i) { f(base + i); };
+				run_section(cnt, g);
+			}
 		}
 		// threads 1..: until thread 0 calls finish()
 		void worker_loop() {
 			unsigned long long seen = 0;
 			for (;;) {
 				unsigned long long e;
-				for (unsigned spins = 0; (e = ticket.load(std::memory_order_acquire) >> 32) == seen; ++spins) {
+				for (unsigned spins = 0; (e = section_of(ticket.load(std::memory_order_acquire))) == seen; ++spins) {
 					if (quit.load(std::memory_order_acquire)) return;
 					relax(spins);
 				}
@@ -239,21 +239,38 @@ class BaTeam {
 		void finish() { quit.store(true, std::memory_order_release); }
 	private:
 		int nthreads;
+		static constexpr unsigned long long MAX_ITEMS = (1ull << 20) - 1, FIELD = (1ull << 20) - 1;
 		unsigned long long section = 0;                      // thread 0 only
-		// (section << 32) | next item: an item is claimed by a compare-exchange on the pair, so a worker that wakes up in a
-		// later section can never take -- or lose -- one of ITS items with a stale function
+		// (section << 40) | (item count << 20) | next item.  An item is claimed by ONE compare-exchange on the whole word, so the
+		// claim itself proves that the section is the live one and that the item lies inside IT.  (The count must not live in a
+		// variable of its own: a worker that read a spent ticket of section e and then the count thread 0 had already written for
+		// section e + 1 -- but before the new ticket was out -- claimed a phantom item n(e) on the OLD ticket, ran it, and its
+		// `done` landed in section e + 1: done == n + 1, thread 0 waits for ever.  Seen once in ~200 estimates on 8 cores.)
+		// A worker would have to sleep through 2^24 sections of one optimize() call to meet its section number again.
 		std::atomic<unsigned long long> ticket{0};
-		std::atomic<int> done{0}, n{0};
+		std::atomic<int> done{0};
 		std::atomic<bool> quit{false};
 		std::atomic<const std::function<void(int)>*> fn{nullptr};
+		static unsigned long long section_of(unsigned long long t) { return t >> 40; }
+		void run_section(int n_items, const std::function<void(int)>& f) {
+			fn.store(&f, std::memory_order_relaxed);
+			done.store(0, std::memory_order_relaxed);
+			section = (section + 1) & ((1ull << 24) - 1);
+			if (section == 0) section = 1;
+			const unsigned long long e = section;
+			ticket.store((e << 40) | ((unsigned long long)n_items << 20), std::memory_order_release);
+			work(e);
+			for (unsigned spins = 0; done.load(std::memory_order_acquire) != n_items; ++spins) relax(spins);
+		}
 		void work(unsigned long long e) {
 			for (;;) {
 				unsigned long long t = ticket.load(std::memory_order_acquire);
-				if ((t >> 32) != e) return;
-				const int i = (int)(unsigned)t;
-				if (i >= n.load(std::memory_order_relaxed)) return;
+				if (section_of(t) != e) return;
+				const unsigned long long i = t & FIELD, cnt = (t >> 20) & FIELD;
+				if (i >= cnt) return;
 				if (!ticket.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
-				(*fn.load(std::memory_order_relaxed))(i);        // the section cannot end (done != n) before this item has
+				// claimed under the live ticket: the section cannot end (done != cnt) before this item has, so fn is this section's
+				(*fn.load(std::memory_order_relaxed))((int)i);
 				done.fetch_add(1, std::memory_order_release);
 			}
 		}

@@ -79,3 +79,20 @@ def test_bundle_adjuster_team_size_changes_no_bit(tmp_path):
         outs.append(np.load(f))
     assert outs[0].shape == (12, 13) and np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_bundle_adjuster_team_sections_end(tmp_path):
+    """BaTeam (pano_camera.hh) hands a section's items out by compare-exchange on ONE word that carries the section number,
+    the item count and the next index.  With the count in a variable of its own a worker holding a spent ticket of section e
+    could read the count of section e + 1, claim a phantom item on the old ticket and leave `done` one too high: thread 0 then
+    spun for ever (one `python bench.py` of the round-6 evidence run sat 15 minutes in the host bundle adjuster).  The harness
+    alternates tiny and large sections of empty items on 8 threads (and oversubscribed): every item exactly once, every
+    section ends.  The form it replaces fails this within 200 k sections (miscount, exit 2, or a section that never ends, exit 3)."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openpano_amd", "host")
+    exe = tmp_path / "ba_team_stress"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-I", host, "-o", str(exe), os.path.join(host, "ba_team_stress.cc")])
+    for threads, sections in ((8, 200000), (24, 30000)):
+        r = subprocess.run([str(exe), str(threads), str(sections)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (threads, r.returncode, r.stderr[-500:])
