@@ -83,7 +83,7 @@ def compact(out):
         line["sift_path_frac_of_hbm_peak"] = pr.get("frac")
     cb = out.get("cpu_baseline")
     if cb:
-        c = _pick(cb, ("value", "unit", "cores", "host_cpus", "cpu_model", "kind", "single_thread_value"))
+        c = _pick(cb, ("value", "unit", "cores", "host_cpus", "cpu_quota", "cpu_model", "kind", "single_thread_value"))
         c["flags"] = _short(cb.get("flags"), 60)
         c["sample"] = _short(cb.get("sample"), 110)
         line["cpu_baseline"] = c
@@ -123,6 +123,8 @@ def compact(out):
             line[key] = _job(out[key])
     if out.get("predicted"):
         line["predicted"] = _pick(out["predicted"], ("sift_ms_per_step", "value"))
+    if out.get("failed_sections"):                       # a secondary section raised: named here, the line itself stands
+        line["failed_sections"] = {k: _short(v, 80) for k, v in list(out["failed_sections"].items())[:6]}
     line["detail"] = DETAIL_FILE
     return _r(line)
 
