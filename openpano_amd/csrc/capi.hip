@@ -40,51 +40,12 @@ void resolve_profile(op_ctx* c) {
 }
 
 // ---- host thread pool ----
-#include <atomic>
-#include <condition_variable>
-#include <thread>
-namespace {
-struct HostPool {
-	std::vector<std::thread> th;
-	std::mutex mu; std::condition_variable cv_work, cv_done;
-	const std::function<void(int)>* body = nullptr;
-	std::atomic<int> next{0}; int n = 0; int active = 0; unsigned long gen = 0; bool stop = false;
-	std::mutex run_mu;      // one parallel loop at a time
-	HostPool() {
-		unsigned hw = std::thread::hardware_concurrency();
-		const int nt = (int)std::min<unsigned>(hw ? hw : 4, 64) - 1;       // (the RANSAC acceptance epilogue of 640 pairs is ~10 ms of serial work)
-		for (int i = 0; i < nt; ++i) th.emplace_back([this] { worker(); });
-	}
-	void drain() { for (int i; (i = next.fetch_add(1)) < n;) (*body)(i); }
-	void worker() {
-		unsigned long seen = 0;
-		std::unique_lock<std::mutex> lk(mu);
-		for (;;) {
-			cv_work.wait(lk, [&] { return stop || gen != seen; });
-			if (stop) return;
-			seen = gen;
-			lk.unlock(); drain(); lk.lock();
-			if (--active == 0) cv_done.notify_all();
-		}
-	}
-	void run(int count, const std::function<void(int)>& f) {
-		std::lock_guard<std::mutex> rl(run_mu);
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			body = &f; n = count; next = 0; active = (int)th.size(); ++gen;
-		}
-		cv_work.notify_all();
-		drain();
-		std::unique_lock<std::mutex> lk(mu);
-		cv_done.wait(lk, [&] { return active == 0; });
-	}
-};
-HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }     // leaked: no join at exit
-}	// namespace
-void host_parallel_for(int n, const std::function<void(int)>& body) {
+#include "host_pool.hpp"
+using ophost::host_pool;
+void host_parallel_for(int n, const std::function<void(int)>& body, int grain) {
 	if (n <= 0) return;
 	if (n == 1) { body(0); return; }
-	host_pool().run(n, body);
+	host_pool().run(n, body, grain < 1 ? 1 : grain);
 }
 
 // ---- device allocation cache ----

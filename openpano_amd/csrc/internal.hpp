@@ -103,7 +103,8 @@ struct HostScope {
 // Host-side parallel loop over [0, n): a persistent pool of std::threads (the process may host
 // several OpenMP runtimes -- PyTorch's, the reference's -- whose interplay cannot be relied on).
 #include <functional>
-void host_parallel_for(int n, const std::function<void(int)>& body);
+// (`grain`: items a woken thread should find -- short items are not worth a thread each)
+void host_parallel_for(int n, const std::function<void(int)>& body, int grain = 1);
 
 // Size-class cache of device allocations (per device, process-wide, thread-safe): result buffers
 // (op_features, op_canvas) and per-call temporaries come from here, so a steady-state call does

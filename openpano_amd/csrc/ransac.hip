@@ -623,25 +623,28 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		// coordinate of the job, fetched once per op_features (the first call waits for it; later ones find it)
 		coor_host = op_features_coor_host(f, ctx);
 		if (!coor_host) { rc = OP_ERR_HIP; goto done; }
+		// what the epilogue needs besides the kernels' results is made while they run: where every pair's points and keypoints
+		// will be, and the order the pairs are judged in (below)
+		{
+			const PairArgs* pa = (const PairArgs*)(pin + u_pa);
+			for (int p = 0; p < npairs; ++p) {
+				PairHost& h = ph[p];
+				h.kp1 = coor_host + fv.offsets[h.i] * 2; h.kp2 = coor_host + fv.offsets[h.j] * 2;
+				if (h.slot >= 0) h.pts = (const double*)(down + r_pts) + (size_t)pa[p].pts_off * 4;
+			}
+		}
+		order = h_active;
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ph[a].m > ph[b].m; });
 		RCHK(hipStreamSynchronize(st));
 	}
 	resolve_profile(ctx);
 	hs.reset(); hs.reset(new HostScope(ctx, "ransac acceptance epilogue (host)"));
-	{
-		const PairArgs* pa = (const PairArgs*)(pin + u_pa);
-		for (int p = 0; p < npairs; ++p) {
-			PairHost& h = ph[p];
-			h.kp1 = coor_host + fv.offsets[h.i] * 2; h.kp2 = coor_host + fv.offsets[h.j] * 2;
-			if (h.slot >= 0) h.pts = (const double*)(down + r_pts) + (size_t)pa[p].pts_off * 4;
-		}
-	}
 
 	// ---- host epilogue per pair (transform_estimate.cc:85-86, 150-218) ----
 	// live pairs only (the others stay at get_transform -> false, :55), longest match lists first: a pair that passes the
-	// first gates counts the keypoints of both images against the overlap polygons (~70 us), most pairs end after a few
-	// microseconds -- dealt in list order the long ones landed at the end of somebody's queue.
-	order = h_active;
-	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ph[a].m > ph[b].m; });
+	// first gates refits the homography on its inliers and counts the keypoints of both images against the overlap polygons
+	// (~30 us), most pairs end after a few microseconds -- dealt in list order the long ones landed at the end of somebody's
+	// queue (`order`, made above while the kernels ran).
 	host_parallel_for(nactive, [&](int q) {
 		const int p = order[q];
 		op_ransac_result::Item& it = R->items[p];
@@ -661,36 +664,33 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		it.inliers = inl;
 		if (inl.size() < 8) return;                                                 // :154
 		double homo[9], inv[9];
-		opransac::calc_transform((int)inl.size(), [&](int q) { return P2{P[4 * inl[q]], P[4 * inl[q] + 1]}; },
-				[&](int q) { return P2{P[4 * inl[q] + 2], P[4 * inl[q] + 3]}; }, affine, homo);   // :179
+		opaccept::calc_transform_skewed((int)inl.size(), [&](int q) { return P2{P[4 * inl[q]], P[4 * inl[q] + 1]}; },
+				[&](int q) { return P2{P[4 * inl[q] + 2], P[4 * inl[q] + 3]}; }, affine, homo);   // :179 (calc_transform's rotations, several rows in flight)
 		if (!inverse3(homo, inv)) return;                                           // :182-184
-		auto match_cnt = [&](const std::vector<P2>& poly, bool first) {
-			if (poly.size() < 3) return 0;
-			PointInPolygon pip(poly);
-			int c = 0;
-			for (int k = 0; k < h.m; ++k) c += pip.in_polygon(first ? P2{P[4 * k], P[4 * k + 1]} : P2{P[4 * k + 2], P[4 * k + 3]}) ? 1 : 0;
-			return c;
+		// the two counts of one overlap polygon (:186-199): the pair's matched points and every keypoint of that image inside it,
+		// eight points per step (count_in_polygon, ransac_accept.hpp).  A polygon of fewer than three vertices: the match count
+		// is 0 (the ratio infinite, the first gate passes) and the reference asserts at the keypoint count (polygon.hh:32)
+		float r1p = 0, r2p = 0;
+		auto gates = [&](const std::vector<P2>& poly, bool first) {
+			int mc = 0, kc = 0;
+			const bool valid = poly.size() >= 3;
+			if (valid) {
+				const PointInPolygon pip(poly);
+				const opaccept::PolygonTables T(pip);
+				mc = opaccept::count_in_polygon(T, P + (first ? 0 : 2), 4, h.m);
+				const float rm = inl.size() * 1.0f / mc;
+				if (rm < cfg->INLIER_IN_MATCH_RATIO) return false;
+				kc = opaccept::count_in_polygon(T, first ? h.kp1 : h.kp2, 2, first ? h.nk1 : h.nk2);
+			}
+			const float rp = inl.size() * 1.0f / kc;
+			if (!valid || rp < 0.01 || rp > 1) return false;
+			(first ? r1p : r2p) = rp;
+			return true;
 		};
-		auto keypoint_cnt = [&](const std::vector<P2>& poly, bool first, bool& valid) {
-			valid = poly.size() >= 3;          // the reference asserts here (polygon.hh:32)
-			if (!valid) return 0;
-			PointInPolygon pip(poly);
-			const double* kp = first ? h.kp1 : h.kp2; const int nk = first ? h.nk1 : h.nk2;
-			int c = 0;
-			for (int k = 0; k < nk; ++k) c += pip.in_polygon(P2{kp[2 * k], kp[2 * k + 1]}) ? 1 : 0;
-			return c;
-		};
-		bool valid = true;
 		std::vector<P2> overlap = overlap_region(h.s1, h.s2, homo, inv);
-		const float r1m = inl.size() * 1.0f / match_cnt(overlap, true);
-		if (r1m < cfg->INLIER_IN_MATCH_RATIO) return;
-		const float r1p = inl.size() * 1.0f / keypoint_cnt(overlap, true, valid);
-		if (!valid || r1p < 0.01 || r1p > 1) return;
+		if (!gates(overlap, true)) return;
 		overlap = overlap_region(h.s2, h.s1, inv, homo);
-		const float r2m = inl.size() * 1.0f / match_cnt(overlap, false);
-		if (r2m < cfg->INLIER_IN_MATCH_RATIO) return;
-		const float r2p = inl.size() * 1.0f / keypoint_cnt(overlap, false, valid);
-		if (!valid || r2p < 0.01 || r2p > 1) return;
+		if (!gates(overlap, false)) return;
 		it.confidence = (float)((r1p + r2p) * 0.5);                                   // :200
 		if (it.confidence < cfg->INLIER_IN_POINTS_RATIO) return;
 		const double area = polygon_area(overlap);
@@ -698,7 +698,7 @@ int op_ransac_pairs(op_ctx* ctx, const op_config* cfg, const op_features* f, con
 		if (area / std::max(area1, area2) < 0.15) return;
 		std::memcpy(it.homo, homo, sizeof(homo));
 		it.ok = 1;
-	});
+	}, 4);
 done:
 	hs.reset();
 #undef RCHK

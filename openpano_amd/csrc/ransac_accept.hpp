@@ -121,6 +121,169 @@ struct PointInPolygon {                               // lib/polygon.hh:30-52, p
 	}
 };
 
+// ---- the keypoint count of the acceptance gates, eight points at a time -------------------------------------------------
+// fill_inliers_to_matchinfo asks in_polygon for every keypoint of both images of every pair that passes the first gates
+// (transform_estimate.cc:191-199): 2 x ~1200 points against a hull of 10-40 vertices, 35 ns each as scalar code -- it WAS
+// the acceptance epilogue (7.8 ms of the 8 ms of serial work of a 703-pair call).  count_in_polygon_v answers the same
+// question for 8 points per step with GCC/clang vector types: every lane performs in_polygon()'s operations in
+// in_polygon()'s order (IEEE add / multiply / divide are the same per lane as scalar; this TU is built without
+// contraction), branches become selects; a lane that needs the reference's own expression (a point within 3e-7 rad of a
+// vertex direction, a zero / non-finite offset) is handed to the scalar in_polygon().  The ISA-specific clones live in
+// ransac_accept_simd.cc (function multiversioning); the harness compares the count with in_polygon_exact point by point.
+template <int W> struct AccVec {
+	typedef double vd __attribute__((vector_size(8 * W)));
+	typedef long long vi __attribute__((vector_size(8 * W)));
+};
+
+// flat copy of what in_polygon() reads, one cache-friendly block per polygon
+struct PolygonTables {
+	const PointInPolygon* pip;
+	std::vector<double> ang;                          // -1e30, the n sorted vertex angles, +1e30: wedge w lies between ang[w] and ang[w + 1]
+	std::vector<double> ax, ay, ex, ey, o1;           // n + 1 wedges: p1, p2 - p1 (the two differences side() forms first), o1
+	explicit PolygonTables(const PointInPolygon& P): pip(&P) {
+		ang.push_back(-1e30); ang.insert(ang.end(), P.ang.begin(), P.ang.end()); ang.push_back(1e30);
+		for (const auto& w : P.wedges) {
+			ax.push_back(w.p1.x); ay.push_back(w.p1.y); ex.push_back(w.p2.x - w.p1.x); ey.push_back(w.p2.y - w.p1.y); o1.push_back(w.o1);
+		}
+	}
+};
+
+// points k = 0..n-1 at xy[k * stride], xy[k * stride + 1]; W lanes per step (8 for 512-bit registers, 4 for 256, 2 for 128)
+template <int W>
+inline __attribute__((always_inline)) int count_in_polygon_v(const PolygonTables& T, const double* xy, size_t stride, int n) {
+	typedef typename AccVec<W>::vd vd;
+	typedef typename AccVec<W>::vi vi;
+#define ACC_SPLAT(v) ((vd){} + (v))
+#define ACC_SEL(m, a, b) ((vd)(((vi)(a) & (m)) | ((vi)(b) & ~(m))))
+#define ACC_ABS(a) ((vd)((vi)(a) & 0x7FFFFFFFFFFFFFFFLL))
+	const PointInPolygon& pip = *T.pip;
+	const int nv = (int)T.ang.size() - 2;
+	const double* ang = T.ang.data();
+	const double* wax = T.ax.data(); const double* way = T.ay.data(); const double* wex = T.ex.data(); const double* wey = T.ey.data(); const double* wo1 = T.o1.data();
+	const vd comx = ACC_SPLAT(pip.com.x), comy = ACC_SPLAT(pip.com.y);
+	constexpr int CH = 256;                                 // points per pass: coordinates transposed once, angles and wedge numbers handed over through memory
+	alignas(64) double xs[CH], ys[CH], ts[CH];
+	alignas(64) long long wedge[CH], scalar[CH];
+	int count = 0;
+	for (int k0 = 0; k0 < n; k0 += CH) {
+		const int m = n - k0 < CH ? n - k0 : CH, mp = (m + W - 1) / W * W;
+		for (int l = 0; l < m; ++l) { xs[l] = xy[(size_t)(k0 + l) * stride]; ys[l] = xy[(size_t)(k0 + l) * stride + 1]; }
+		for (int l = m; l < mp; ++l) { xs[l] = 0; ys[l] = 0; }                       // padding lanes: computed, never read
+		for (int b = 0; b < mp; b += W) {
+			const vd px = *(const vd*)(xs + b), py = *(const vd*)(ys + b);
+			const vd y = py - comy, x = px - comx;
+			// fast_atan2(y, x), lane for lane
+			const vd ay = ACC_ABS(y), ax = ACC_ABS(x);
+			const vi gt = ax > ay;
+			const vd hi = ACC_SEL(gt, ax, ay), lo = ACC_SEL(gt, ay, ax);
+			vd a = lo / hi;
+			const vi big = a > ACC_SPLAT(0.41421356237309503);
+			a = ACC_SEL(big, (a - ACC_SPLAT(1.0)) / (a + ACC_SPLAT(1.0)), a);
+			const vd base = ACC_SEL(big, ACC_SPLAT(0.78539816339744828), ACC_SPLAT(0.0));
+			const vd s = a * a;
+			vd p = ACC_SPLAT(0.047129968897061815);
+			p = p * s + ACC_SPLAT(-0.08459108968229646); p = p * s + ACC_SPLAT(0.11041054122251703); p = p * s + ACC_SPLAT(-0.14281639256027157);
+			p = p * s + ACC_SPLAT(0.19999885898543113); p = p * s + ACC_SPLAT(-0.3333333212787719); p = p * s + ACC_SPLAT(0.9999999999791288);
+			vd r = base + a * p;
+			r = ACC_SEL(ay > ax, ACC_SPLAT(1.5707963267948966) - r, r);
+			r = ACC_SEL((vi)x < 0, ACC_SPLAT(3.141592653589793) - r, r);                // signbit(x)
+			const vd t = ACC_SEL((vi)y < 0, -r, r);                                       // signbit(y)
+			// wedge = number of vertex angles below t (t - ang > 0 exactly when t > ang: a difference of two doubles is never rounded to zero)
+			vi below = {};
+			for (int i = 1; i <= nv; ++i) below -= t > ACC_SPLAT(ang[i]);                 // a true lane is -1
+			// libm decides zero / non-finite offsets (fast_atan2's first line) and whatever made t a NaN
+			*(vi*)(scalar + b) = ~(hi > ACC_SPLAT(0.0)) | ~(hi < ACC_SPLAT(1.7976931348623157e308)) | (t != t);
+			*(vi*)(wedge + b) = below; *(vd*)(ts + b) = t;
+		}
+		// per point: the nearest vertex angle is one of the wedge's two (the angles are sorted) -- within 3e-7 of t the float rounding of the
+		// reference's k could matter and its own expression decides; otherwise decide(): !(o1 * side(p1, p2, p) < -1e-6) with the wedge's edge
+		for (int l = 0; l < m; ++l) {
+			const int w = (int)wedge[l];
+			const double dl = ts[l] - ang[w], dr = ang[w + 1] - ts[l];
+			if (scalar[l] || !((dl < dr ? dl : dr) > 3e-7)) { count += pip.in_polygon(P2{xs[l], ys[l]}) ? 1 : 0; continue; }
+			const double sd = wex[w] * (ys[l] - way[w]) - wey[w] * (xs[l] - wax[w]);
+			count += !(wo1[w] * sd < -1e-6) ? 1 : 0;
+		}
+	}
+#undef ACC_SPLAT
+#undef ACC_SEL
+#undef ACC_ABS
+	return count;
+}
+// the dispatching entry (ransac_accept_simd.cc): 512- / 256- / 128-bit clones of the loop above
+int count_in_polygon(const PolygonTables& T, const double* xy, size_t stride, int n);
+
+// ---- the refit on all inliers (transform_estimate.cc:179), rows in flight ----------------------------------------------------
+// opransac::calc_transform feeds the least-squares rows to GivensLS one at a time: 2 n rows x up to NV rotations, every
+// rotation a chain of square root -> divide -> multiply -> add that the next one waits for (40 cycles each: 23 us for the
+// 122 inliers of an average accepted pair -- the largest piece of an accepted pair's epilogue once the keypoint count was
+// vectorised).  Rotation (row r, column k) needs only (r - 1, k) and (r, k - 1): the rotations with r + k = t are independent
+// of each other.  calc_transform_skewed walks the (row, column) grid by anti-diagonals, so up to NV chains are in flight in
+// the core's out-of-order window instead of one.  Every rotation reads and writes exactly the values it reads and writes in
+// the row-by-row order: the triangle, and the homography, are bit-identical (the harness compares them).  Host only.
+template <int NV>
+inline void givens_rows_skewed(opransac::GivensLS<NV>& ls, double* rows, int nrows) {     // rows: nrows x (NV + 1), [a | beta]
+	constexpr int S = NV + 1;
+	for (int t = 0; t < nrows + NV - 1; ++t) {
+		const int k_lo = t - (nrows - 1) > 0 ? t - (nrows - 1) : 0, k_hi = t < NV - 1 ? t : NV - 1;
+		for (int k = k_lo; k <= k_hi; ++k) {
+			double* a = rows + (size_t)(t - k) * S;
+			const double ak = a[k];
+			if (ak == 0.0) continue;
+			const double rkk = ls.R[k][k];
+			const double r = std::sqrt(rkk * rkk + ak * ak);
+			const double c = rkk / r, sn = ak / r;
+			ls.R[k][k] = r;
+			for (int j = k + 1; j < NV; ++j) {
+				const double tt = c * ls.R[k][j] + sn * a[j];
+				a[j] = c * a[j] - sn * ls.R[k][j];
+				ls.R[k][j] = tt;
+			}
+			const double tt = c * ls.qtb[k] + sn * a[NV];
+			a[NV] = c * a[NV] - sn * ls.qtb[k];
+			ls.qtb[k] = tt;
+		}
+	}
+}
+
+template <typename Get1, typename Get2>
+inline void calc_transform_skewed(int n, Get1 get1, Get2 get2, bool affine, double (&H)[9]) {
+	if (n < 16) { opransac::calc_transform(n, get1, get2, affine, H); return; }
+	const double s1 = opransac::norm_scale(n, get1), s2 = opransac::norm_scale(n, get2);
+	double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
+	if (!affine) {
+		std::vector<double> rows((size_t)2 * n * 9);
+		for (int i = 0; i < n; ++i) {                        // lib/imgproc.cc:267-274: rows 0..n-1 the x equations, n..2n-1 the y equations
+			P2 m0 = get1(i), m1 = get2(i);
+			m0.x *= s1; m0.y *= s1; m1.x *= s2; m1.y *= s2;
+			const double rx[9] = {m1.x, m1.y, 1, 0, 0, 0, -m1.x * m0.x, -m1.y * m0.x, m0.x};
+			const double ry[9] = {0, 0, 0, m1.x, m1.y, 1, -m1.x * m0.y, -m1.y * m0.y, m0.y};
+			std::memcpy(&rows[(size_t)i * 9], rx, sizeof(rx)); std::memcpy(&rows[(size_t)(n + i) * 9], ry, sizeof(ry));
+		}
+		opransac::GivensLS<8> ls; ls.reset();
+		givens_rows_skewed<8>(ls, rows.data(), 2 * n);
+		double x[8];
+		ls.solve(x);
+		for (int i = 0; i < 8; ++i) h[i] = x[i];
+	} else {
+		std::vector<double> rows((size_t)2 * n * 7);
+		for (int i = 0; i < n; ++i) {                        // lib/imgproc.cc:304-310: rows interleaved x, y per point
+			P2 m0 = get1(i), m1 = get2(i);
+			m0.x *= s1; m0.y *= s1; m1.x *= s2; m1.y *= s2;
+			const double r0[7] = {m1.x, m1.y, 1, 0, 0, 0, m0.x}, r1[7] = {0, 0, 0, m1.x, m1.y, 1, m0.y};
+			std::memcpy(&rows[(size_t)(2 * i) * 7], r0, sizeof(r0)); std::memcpy(&rows[(size_t)(2 * i + 1) * 7], r1, sizeof(r1));
+		}
+		opransac::GivensLS<6> ls; ls.reset();
+		givens_rows_skewed<6>(ls, rows.data(), 2 * n);
+		double x[6];
+		ls.solve(x);
+		for (int i = 0; i < 6; ++i) h[i] = x[i];
+	}
+	const double i1 = 1.0 / s1;                                // t1.inverse() * H * t2 with t = diag(s, s, 1) (transform_estimate.cc:121-128)
+	const double l[3] = {i1, i1, 1.0}, r[3] = {s2, s2, 1.0};
+	for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) H[a * 3 + b] = (l[a] * h[a * 3 + b]) * r[b];
+}
+
 inline P2 trans2d(const double (&H)[9], P2 m) {       // homography.hh:53-76
 	const double x = H[0] * m.x + H[1] * m.y + H[2] * 1.0, y = H[3] * m.x + H[4] * m.y + H[5] * 1.0, z = H[6] * m.x + H[7] * m.y + H[8] * 1.0;
 	const double d = 1.0 / z;

@@ -21,7 +21,7 @@ for src in $srcs; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fopenmp -I../../include -I. -Wall -Wno-unused-function -Wno-unused-value $flags -c $work/$src -o $work/${src%.hip}.o &
 done
 wait
-objs=""
+objs="ransac_accept_simd.o"                  # host-only TU, never a variant
 for f in *.hip; do
   if [[ " $srcs " == *" $f "* ]]; then objs="$objs $work/${f%.hip}.o"; else objs="$objs ${f%.hip}.o"; fi
 done
