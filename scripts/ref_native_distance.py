@@ -73,18 +73,18 @@ def workload(quick):
     import natural
     views = []
     n2, n3, n4 = (2, 0, 2) if quick else (4, 3, 6)
-    for k, v in enumerate(synth.image_set(11, 400, 600, seed=22, overlap=0.40)[:n2]):
+    for k, v in enumerate(synth.image_set(11, 400, 600, seed=22, overlap=0.40, first=n2) if n2 else []):
         views.append((f"cfg2_synth_{k}", v))
-    for k, v in enumerate(synth.image_set(13, 1112, 1500, seed=33, overlap=0.40)[:n3]):
+    for k, v in enumerate(synth.image_set(13, 1112, 1500, seed=33, overlap=0.40, first=n3) if n3 else []):
         views.append((f"cfg3_synth_{k}", v))
-    for k, v in enumerate(synth.image_set(38, 867, 1300, seed=38, overlap=0.45, rows=2)[:n4]):   # grid order: neighbours overlap
+    for k, v in enumerate(synth.image_set(4 if quick else 38, 867, 1300, seed=38, overlap=0.45, rows=2, first=n4) if n4 else []):   # grid order: neighbours overlap (quick: a 4-view world -- the 38-view one takes minutes to paint)
         views.append((f"cfg4_synth_{k}", v))
     if natural.available():
-        for k, v in enumerate(natural.config_views(1)):
+        for k, v in enumerate(natural.config_views(1)[: 1 if quick else None]):
             views.append((f"cfg1_nat_uav_{k}", natural.u8_to_f32(v)))
         for k, v in enumerate(natural.config_views(2, 2 if quick else 4)):
             views.append((f"cfg2_nat_cmu_{k}", natural.u8_to_f32(v)))
-        for c in range(2 if quick else 4):
+        for c in range(1 if quick else 4):
             views.append((f"cfg4_nat_uav_{c}", natural.u8_to_f32(natural.crop_u8("uav", 60, 60 + 140 * c, 867, 1300, seed=3800 + c))))
     return views
 
