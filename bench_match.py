@@ -235,6 +235,11 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
     barrier(); t0 = time.perf_counter()
     ph, k, nm, ok, inl, prof = one_pass(True)
     wall = (time.perf_counter() - t0) * 1e3
+    # the RANSAC phase's own stage table, from one more (untimed) call with the stage events on
+    ctx.set_profiling(True); ctx.profile_reset()
+    job.ransac_summary(shapes, 1)
+    rprof = {kk: v[0] for kk, v in ctx.profile().items() if kk.startswith("ransac")}
+    ctx.set_profiling(False)
     mine = job.my_pairs
     flops = sum(2.0 * 128 * job.gcounts[i] * job.gcounts[j] for i, j in mine)
     names = list(ph)
@@ -263,6 +268,7 @@ def run_strong_job(hip, ctx, cfg, kind, args, dist, dev, rank, world, barrier, l
            "match_rate_span": match_span_note,
            "match_stage_ms": {x: round(v, 4) for x, v in prof.items() if x.startswith("matcher")},
            "sift_stage_ms": {x: round(v, 4) for x, v in prof.items() if not x.startswith("matcher")},
+           "ransac_stage_ms": {x: round(v, 4) for x, v in rprof.items()},
            "match_roofline": _mfma_roofline(prof, flops, getattr(args, "pmc", None), getattr(args, "pmc_src", None)),
            "allgather_bytes_per_rank": int(max(sum(job.counts), 1) * 528) if dist is not None else None}
     if kind == "config5" and res["match_roofline"] is not None:

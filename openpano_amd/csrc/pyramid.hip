@@ -42,7 +42,16 @@ __device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p
 // octave pixel has exactly one such tile).  The working image never goes to HBM (the staged dump
 // asks for it with write_work); every value is computed by the reference's formulas, so the grey
 // planes are bit-identical to the two-pass result.
-constexpr int WT = 64, WR = 16;               // working-image tile
+// 64 x 14: the (WR + 1) x (WT + 1) = 975 tile elements are 3.8 per thread -- four rounds of 256 lanes with 5 % of them idle; at
+// 64 x 16 (1105 elements) the fifth round ran 81 lanes of 256, and its 12 more load registers cost two resident wavefronts per
+// SIMD (82 -> 70 VGPRs: 5 -> 7).  Measured 12 / 14 / 16 / 20 / 22 rows: 0.1742 / 0.1634 / 0.1713 / 0.1770 / 0.1764 ms
+// (profiles/r06_grey_tile_rows.txt).  (Walking only the run of octave candidates that belong to the tile -- the rectangle
+// below is conservative: 10 x 35 candidates for 7 x 32 pixels at octave 1 -- was measured too: the threads that find the run's
+// ends between the two barriers cost more than the round of 256 lanes they save, 0.1683 -> 0.1736 ms.)
+#ifndef OP_GREY_WR
+#define OP_GREY_WR 14
+#endif
+constexpr int WT = 64, WR = OP_GREY_WR;       // working-image tile
 constexpr int WP = WT + 1 + 2;                // LDS pitch (WT + 1 columns used)
 
 // six consecutive source elements from i (element-aligned only) -- fp32 as they are: one 16-byte and one 8-byte load; or

@@ -506,22 +506,37 @@ class ShardedJob:
         self.rres = out
         return sum(1 for r in self.rres if r["ok"])
 
+    def _pairs_np(self):
+        """my_pairs as an (P, 2) int32 array, made once per deal (the RANSAC summary call marshals 8128 pairs per pass otherwise:
+        list comprehensions and np.asarray of a list of tuples were ~3 ms of a config-5 job's 11-ms RANSAC phase)"""
+        c = getattr(self, "_pairs_cache", None)
+        if c is None or c[0] is not self.my_pairs:
+            c = (self.my_pairs, np.ascontiguousarray(np.asarray(self.my_pairs, np.int32).reshape(-1, 2)))
+            self._pairs_cache = c
+        return c[1]
+
     def ransac_summary(self, shapes_wh, base_seed=1):
         """RANSAC over this rank's pairs without unpacking every pair into Python (HipEngine) -> (accepted pairs, inliers)"""
-        seeds = self.seeds(base_seed)
-        rest = self._rest()
+        pr = self._pairs_np()
+        seeds = ((int(base_seed) + pr[:, 0].astype(np.int64) * self.n + pr[:, 1]) & 0xFFFFFFFF).astype(np.uint32)   # == self.seeds()
+        sh = np.ascontiguousarray(np.asarray(shapes_wh, np.int32).reshape(-1, 2))
+        if not self.local_sel:                       # every pair was matched in one call (N = 1, or no pair of two own images)
+            return self.e.ransac_summary(self.tab, self.mh, pr, sh, seeds) if len(pr) else (0, 0)
+        rest = np.asarray(self._rest(), np.int64)
+        local = np.asarray(list(self.local_sel), np.int64)
         order, joined = self._joined()
         if joined is not None:
             try:
-                return self.e.ransac_summary(self.tab, joined, [self.my_pairs[k] for k in order], shapes_wh, [seeds[k] for k in order])
+                o = np.asarray(order, np.int64)
+                return self.e.ransac_summary(self.tab, joined, pr[o], sh, seeds[o])
             finally:
                 self.e.free(joined)
         ok = inl = 0
-        if rest:
-            a, b = self.e.ransac_summary(self.tab, self.mh, [self.my_pairs[k] for k in rest], shapes_wh, [seeds[k] for k in rest])
+        if len(rest):
+            a, b = self.e.ransac_summary(self.tab, self.mh, pr[rest], sh, seeds[rest])
             ok += a; inl += b
-        if self.local_sel:
-            a, b = self.e.ransac_summary(self.local_tab, self.local_mh, self.local_pairs, [shapes_wh[g] for g in self.local_ids], [seeds[k] for k in self.local_sel])
+        if len(local):
+            a, b = self.e.ransac_summary(self.local_tab, self.local_mh, self.local_pairs, [shapes_wh[g] for g in self.local_ids], seeds[local])
             ok += a; inl += b
         return ok, inl
 
