@@ -234,3 +234,39 @@ def test_joined_match_handles_give_the_single_call_results(ctx, cfg):
         j.free()
     assert sum(1 for w in want if w["ok"]) >= 3
     a.free(); b.free(); whole.free(); f.free()
+
+
+def test_results_do_not_depend_on_the_host_pool_size(tmp_path):
+    """The acceptance epilogue runs on the library's host pool (csrc/host_pool.hpp); which thread judges a pair, how many
+    threads there are (OPENPANO_HOST_THREADS) and which ISA clone counts the keypoints change no bit of any pair's result:
+    the same job in three processes -- the calling thread only, three threads, the default pool -- gives one digest."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from openpano_amd import hip, synth\nfrom openpano_amd.config import PanoConfig\n"
+            "cfg = PanoConfig(); c = hip.Context(0)\n"
+            "n = 8; views = synth.image_set(n, 400, 600, seed=22, overlap=0.45)\n"
+            "f = hip.sift_batch(c, cfg, views); pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]\n"
+            "mh = hip.match_pairs_handle(c, cfg, f, pairs)\n"
+            "crc = 0\n"
+            "for rep in range(3):\n"
+            "    for r in hip.ransac_pairs(c, cfg, f, mh, pairs, [(600, 400)] * n, base_seed=11):\n"
+            "        crc = zlib.crc32(np.asarray([r['ok'], r['best_hyp'], r['best_count']], np.int64).tobytes(), crc)\n"
+            "        crc = zlib.crc32(np.float32(r['confidence']).tobytes(), crc)\n"
+            "        crc = zlib.crc32(np.ascontiguousarray(r['homo'], np.float64).tobytes(), crc)\n"
+            "        crc = zlib.crc32(np.ascontiguousarray(r['inliers'], np.int32).tobytes(), crc)\n"
+            "print('DIGEST', crc, sum(1 for r in hip.ransac_pairs(c, cfg, f, mh, pairs, [(600, 400)] * n, base_seed=11) if r['ok']))\n") % root
+    digests = []
+    for threads in ("1", "3", None):
+        env = dict(os.environ)
+        env.pop("OPENPANO_HOST_THREADS", None)
+        if threads:
+            env["OPENPANO_HOST_THREADS"] = threads
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1].split()
+        digests.append((line[1], line[2]))
+    assert digests[0] == digests[1] == digests[2], digests
+    assert int(digests[0][1]) >= 3          # overlapping neighbours of the strip are accepted: the gates' counts were exercised
